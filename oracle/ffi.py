@@ -1,0 +1,247 @@
+"""ctypes front-end of oracle/libturtle_oracle.so (TEST INFRASTRUCTURE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  It builds the library with gcc on first use if the .so is missing
+(it is git-ignored but travels to the GPU box with the snapshot).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libturtle_oracle.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+LAYOUT_DEFAULT, LAYOUT_HGT = 0, 1
+FLAT, MAP, STACK = 0, 1, 2
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "turtle_oracle.c")
+    stale = (not os.path.exists(LIB_PATH)) or (
+        os.path.getmtime(LIB_PATH) < os.path.getmtime(src))
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", HERE, LIB_PATH])
+    return LIB_PATH
+
+
+class Grid(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int),
+                ("x0", C.c_double), ("y0", C.c_double),
+                ("dx", C.c_double), ("dy", C.c_double),
+                ("z0", C.c_double), ("dz", C.c_double),
+                ("layout", C.c_int), ("data", C.c_void_p)]
+
+
+class Stack(C.Structure):
+    _fields_ = [("lat0", C.c_double), ("lon0", C.c_double),
+                ("dlat", C.c_double), ("dlon", C.c_double),
+                ("nlat", C.c_int), ("nlon", C.c_int), ("tile", C.c_void_p)]
+
+
+class Meta(C.Structure):
+    _fields_ = [("kind", C.c_int), ("src", C.c_int), ("offset", C.c_double)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("layer_first", C.c_void_p),
+                ("metas", C.c_void_p), ("grids", C.c_void_p),
+                ("stacks", C.c_void_p), ("geoid", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_trace_n.restype = C.c_long
+        L.orc_grid_node.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_grid_raw(nodes: np.ndarray, z0: float, z1: float) -> np.ndarray:
+    """Encode elevations the way turtle_map_fill does (map.c:47-51): uint16
+    round((z - z0)/dz), dz = (z1 - z0)/65535 (map.c:85); rows south->north."""
+    dz = (z1 - z0) / 65535
+    # C round() is half-away-from-zero; np.round is half-even.  Values here are
+    # >= 0, so floor(x + 0.5) reproduces C.
+    d = np.floor((np.asarray(nodes, dtype=np.float64) - z0) / dz + 0.5)
+    return d.astype(np.uint16)
+
+
+class OracleGeometry:
+    """Flattened description of a stepper geometry for the oracle.
+
+    grids : list of dict(nx, ny, x0, y0, dx, dy, z0, dz, layout, data[uint16 array])
+    stacks: list of dict(lat0, lon0, dlat, dlon, nlat, nlon, tile[int array])
+    layers: list (bottom->top) of lists of (kind, src, offset) in the order the
+            user ADDED them; the reference iterates last-added first and so do
+            the flattened metas.
+    """
+
+    def __init__(self, grids=(), stacks=(), layers=(), geoid=-1):
+        self._keep = []
+        self.grids = (Grid * max(1, len(grids)))()
+        for i, g in enumerate(grids):
+            data = np.ascontiguousarray(g["data"]).view(np.uint16).reshape(-1)
+            assert data.size == g["nx"] * g["ny"]
+            self._keep.append(data)
+            self.grids[i] = Grid(g["nx"], g["ny"], g["x0"], g["y0"], g["dx"],
+                                 g["dy"], g["z0"], g["dz"], g["layout"],
+                                 data.ctypes.data)
+        self.stacks = (Stack * max(1, len(stacks)))()
+        for i, s in enumerate(stacks):
+            tile = np.ascontiguousarray(s["tile"], dtype=np.int32).reshape(-1)
+            self._keep.append(tile)
+            self.stacks[i] = Stack(s["lat0"], s["lon0"], s["dlat"], s["dlon"],
+                                   s["nlat"], s["nlon"], tile.ctypes.data)
+        first, metas = [0], []
+        for layer in layers:
+            for kind, src, offset in reversed(list(layer)):
+                metas.append((kind, src, offset))
+            first.append(len(metas))
+        self.layer_first = np.asarray(first, dtype=np.int32)
+        self.metas = (Meta * max(1, len(metas)))()
+        for i, m in enumerate(metas):
+            self.metas[i] = Meta(*m)
+        self.n_layers = len(layers)
+        self.struct = Geometry(
+            self.n_layers, self.layer_first.ctypes.data,
+            C.cast(self.metas, C.c_void_p), C.cast(self.grids, C.c_void_p),
+            C.cast(self.stacks, C.c_void_p), geoid)
+
+    @property
+    def ref(self):
+        return C.byref(self.struct)
+
+    # ---- batch entry points -------------------------------------------
+    def trace(self, position, direction, max_steps=100000, slope=0.4,
+              resolution=1e-2, local_range=0.0, threads=1):
+        pos = np.array(position, dtype=np.float64, order="C").reshape(-1, 3)
+        dire = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+        n = pos.shape[0]
+        index = np.empty((n, 2), dtype=np.int32)
+        length = np.empty(n, dtype=np.float64)
+        nsteps = np.empty(n, dtype=np.int32)
+        samples = C.c_long(0)
+        total = lib().orc_trace_n(
+            self.ref, C.c_double(slope), C.c_double(resolution),
+            C.c_double(local_range), C.c_long(n), _p(pos), _p(dire),
+            C.c_int(max_steps), _p(index), _p(length), _p(nsteps),
+            C.c_int(threads), C.byref(samples))
+        return dict(position=pos, index=index, length=length, n_steps=nsteps,
+                    total_steps=int(total), total_samples=int(samples.value))
+
+    def step(self, position, direction=None, slope=0.4, resolution=1e-2):
+        pos = np.array(position, dtype=np.float64, order="C").reshape(-1, 3)
+        n = pos.shape[0]
+        dire = None if direction is None else np.ascontiguousarray(
+            direction, dtype=np.float64).reshape(-1, 3)
+        out = dict(latitude=np.empty(n), longitude=np.empty(n),
+                   altitude=np.empty(n), elevation=np.empty((n, 2)),
+                   step=np.empty(n), index=np.empty((n, 2), dtype=np.int32))
+        lib().orc_step_n(
+            self.ref, C.c_double(slope), C.c_double(resolution), C.c_long(n),
+            _p(pos), _p(dire), _p(out["latitude"]), _p(out["longitude"]),
+            _p(out["altitude"]), _p(out["elevation"]), _p(out["step"]),
+            _p(out["index"]))
+        out["position"] = pos
+        return out
+
+    def position(self, latitude, longitude, height, layer=0):
+        lat = np.ascontiguousarray(latitude, dtype=np.float64)
+        lon = np.ascontiguousarray(longitude, dtype=np.float64)
+        h = np.ascontiguousarray(np.broadcast_to(height, lat.shape), dtype=np.float64)
+        n = lat.size
+        pos = np.zeros((n, 3))
+        di = np.empty(n, dtype=np.int32)
+        lib().orc_position_n(self.ref, C.c_long(n), _p(lat), _p(lon), _p(h),
+                             C.c_int(layer), _p(pos), _p(di))
+        return pos, di
+
+    def grid_elevation(self, grid, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        z = np.empty(x.size)
+        inside = np.empty(x.size, dtype=np.int32)
+        lib().orc_grid_elevation_n(C.byref(self.grids[grid]), C.c_long(x.size),
+                                   _p(x), _p(y), _p(z), _p(inside))
+        return z, inside
+
+    def stack_elevation(self, stack, latitude, longitude):
+        lat = np.ascontiguousarray(latitude, dtype=np.float64)
+        lon = np.ascontiguousarray(longitude, dtype=np.float64)
+        z = np.empty(lat.size)
+        inside = np.empty(lat.size, dtype=np.int32)
+        lib().orc_stack_elevation_n(self.ref, C.c_int(stack), C.c_long(lat.size),
+                                    _p(lat), _p(lon), _p(z), _p(inside))
+        return z, inside
+
+
+def ecef_to_geodetic(ecef):
+    e = np.ascontiguousarray(ecef, dtype=np.float64).reshape(-1, 3)
+    n = e.shape[0]
+    lat, lon, alt = np.empty(n), np.empty(n), np.empty(n)
+    lib().orc_ecef_to_geodetic_n(C.c_long(n), _p(e), _p(lat), _p(lon), _p(alt))
+    return lat, lon, alt
+
+
+def ecef_from_geodetic(latitude, longitude, elevation):
+    lat = np.ascontiguousarray(latitude, dtype=np.float64)
+    lon = np.ascontiguousarray(longitude, dtype=np.float64)
+    el = np.ascontiguousarray(elevation, dtype=np.float64)
+    out = np.empty((lat.size, 3))
+    lib().orc_ecef_from_geodetic_n(C.c_long(lat.size), _p(lat), _p(lon), _p(el), _p(out))
+    return out
+
+
+def ecef_from_horizontal(latitude, longitude, azimuth, elevation):
+    a = [np.ascontiguousarray(v, dtype=np.float64)
+         for v in (latitude, longitude, azimuth, elevation)]
+    out = np.empty((a[0].size, 3))
+    lib().orc_ecef_from_horizontal_n(C.c_long(a[0].size), *map(_p, a), _p(out))
+    return out
+
+
+def ecef_to_horizontal(latitude, longitude, direction):
+    lat = np.ascontiguousarray(latitude, dtype=np.float64)
+    lon = np.ascontiguousarray(longitude, dtype=np.float64)
+    d = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+    az, el = np.zeros(lat.size), np.zeros(lat.size)
+    lib().orc_ecef_to_horizontal_n(C.c_long(lat.size), _p(lat), _p(lon), _p(d), _p(az), _p(el))
+    return az, el
+
+
+# ---- convenience builders for the synthetic terrains of turtle_amd.synth ----
+
+def hgt_grid(lat0, lon0, nodes_s2n):
+    """Grid dict holding the RAW .hgt payload (big-endian, north row first),
+    with the meta hgt_open derives from the file name (hgt.c:59-104)."""
+    n = nodes_s2n.shape[0]
+    raw = np.ascontiguousarray(nodes_s2n[::-1, :]).astype(">i2").view(np.uint16)
+    return dict(nx=n, ny=n, x0=float(lon0), y0=float(lat0), dx=1.0 / (n - 1),
+                dy=1.0 / (n - 1), z0=-32767.0, dz=1.0, layout=LAYOUT_HGT, data=raw)
+
+
+def default_grid(nodes_s2n, x, y, z):
+    """Grid dict as turtle_map_create + turtle_map_fill would hold it (map.c:54-99)."""
+    ny, nx = nodes_s2n.shape
+    dx = (x[1] - x[0]) / (nx - 1) if nx > 1 else 0.0
+    dy = (y[1] - y[0]) / (ny - 1) if ny > 1 else 0.0
+    return dict(nx=nx, ny=ny, x0=float(x[0]), y0=float(y[0]), dx=dx, dy=dy,
+                z0=float(z[0]), dz=(z[1] - z[0]) / 65535, layout=LAYOUT_DEFAULT,
+                data=default_grid_raw(nodes_s2n, z[0], z[1]))
