@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- ray-steps/s of the trace kernel on the BASELINE workload.
+
+Workload (BASELINE.json configs[1], "C2"): 1 M rays per GPU through one
+synthetic 3601x3601 SRTMGL1 tile (turtle_amd.synth), rays from the common
+recipe of SURVEY.md 8d: origin uniform over the tile 500 m above ground,
+azimuth U[0,360), elevation U[-10,-1] deg, slope 0.4, resolution 1e-2, traced
+until the medium changes (hit or exit).  One "step" of this benchmark = one
+turtle_stepper_trace_n call over the whole batch, inputs resident in HBM.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), tile
+replicated, rays block-sharded (rank r draws its own Philox block), no
+data-path collective; the per-step tally (hit counts + 1024-bin path-length
+histogram, uint64) is all-reduced.  Weak scaling: per-GPU work is fixed.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+TRACE_KERNEL = "k_trace"
+
+
+def cpu_baseline(nodes, n_rays, seed):
+    """The CPU restatement (oracle/, kind "port") on a bounded sample of the
+    same workload, all host cores, exact transform (range 0) and the
+    reference's default local-linear approximation (range 1)."""
+    from oracle import ffi as O
+    geo = O.OracleGeometry(grids=[O.hgt_grid(45, 3, nodes)], layers=[[(O.MAP, 0, 0.0)]])
+    from turtle_amd import synth
+    lat, lon, az, el = synth.uniform_rays(n_rays, (45.0, 46.0), (3.0, 4.0), seed=seed)
+    pos, _ = geo.position(lat, lon, 500.0)
+    d = O.ecef_from_horizontal(lat, lon, az, el)
+    cores = len(os.sched_getaffinity(0))
+    out = {}
+    for tag, rng in (("range0", 0.0), ("range1", 1.0)):
+        t0 = time.perf_counter()
+        r = geo.trace(pos, d, local_range=rng, threads=cores)
+        dt = time.perf_counter() - t0
+        out[tag] = r["total_steps"] / dt
+        out[tag + "_s"] = dt
+    t0 = time.perf_counter()
+    one = geo.trace(pos[: max(1, n_rays // cores)], d[: max(1, n_rays // cores)],
+                    local_range=0.0, threads=1)
+    out["one_core"] = one["total_steps"] / (time.perf_counter() - t0)
+    return out, cores, r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rays", type=int, default=1_000_000, help="rays per GPU")
+    ap.add_argument("--max-steps", type=int, default=100_000)
+    ap.add_argument("--cpu-rays", type=int, default=200_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import turtle_amd as TA
+    from turtle_amd import synth
+
+    # ---- terrain: the synthetic SRTMGL1 tile, loaded through the C API ----
+    nodes = synth.srtm_like_nodes(45, 3)
+    tmp = tempfile.mkdtemp(prefix=f"turtle_bench_{rank}_")
+    tile = TA.Map.load(synth.write_hgt(tmp, 45, 3))
+    stepper = TA.Stepper()
+    stepper.add_map(tile, 0.0)
+    TA.set_stream(torch.cuda.current_stream())
+
+    # ---- rays: rank r draws block r of the Philox stream; set-up on the GPU ----
+    n = args.rays
+    lat, lon, az, el = synth.uniform_rays(n, (45.0, 46.0), (3.0, 4.0),
+                                          seed=0x5EED2026 + rank)
+    dev = torch.device("cuda", local)
+    t_lat, t_lon, t_az, t_el = (torch.as_tensor(v, device=dev) for v in (lat, lon, az, el))
+    pos0, di = stepper.position(t_lat, t_lon, 500.0)
+    direction = TA.ecef_from_horizontal(t_lat, t_lon, t_az, t_el)
+    assert int((di != 0).sum()) == 0
+    pos = torch.empty_like(pos0)
+    index = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    length = torch.empty(n, dtype=torch.float64, device=dev)
+    nsteps = torch.empty(n, dtype=torch.int32, device=dev)
+    n_media, n_bins, lmax = 2, 1024, 65536.0
+    tally = torch.zeros(n_media + 1 + n_bins + 1 + 1, dtype=torch.int64, device=dev)
+
+    def one_step():
+        pos.copy_(pos0)                      # the trace advances positions in place
+        stepper.trace_into(pos, direction, index, length, nsteps, args.max_steps)
+
+    def reduce_tally():
+        tally.zero_()
+        TA.tally(index, length, n_media, n_bins, lmax, tally[: n_media + 1],
+                 tally[n_media + 1: n_media + 1 + n_bins + 1])
+        tally[-1] = nsteps.sum(dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(tally)           # RCCL, ~8 KB: the only collective
+
+    for _ in range(args.warmup):
+        one_step()
+        reduce_tally()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        pos.copy_(pos0)
+        ev[k][0].record()
+        stepper.trace_into(pos, direction, index, length, nsteps, args.max_steps)
+        ev[k][1].record()
+        reduce_tally()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    elapsed = float(t_all.item())
+
+    stats = stepper.trace_stats()            # of the last launch on this rank
+    total_steps_per_pass = int(tally[-1].item())   # all ranks (all-reduced)
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    if rank == 0:
+        value = total_steps_per_pass * args.steps / elapsed
+        # algorithmic bytes of one launch: 4 x 2 B nodes per sample
+        # + per ray 48 B in (pos, dir) + 44 B out (pos, index, length, n_steps)
+        alg_bytes = 8.0 * stats["samples"] + 92.0 * stats["rays"]
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "ray-steps/sec (whole node) through 3601^2 SRTM tile",
+            "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: 1M rays/GPU, one 3601x3601 SRTMGL1 tile, "
+                                   "trace to first boundary",
+                       "rays_per_gpu": n, "max_steps": args.max_steps,
+                       "slope": 0.4, "resolution": 1e-2, "parallelism": f"rays x{world}"},
+            "kernel": {"name": TRACE_KERNEL, "ms": kernel_ms,
+                       "steps_per_launch": stats["steps"],
+                       "samples_per_launch": stats["samples"],
+                       "samples_per_step": stats["samples"] / max(1, stats["steps"]),
+                       "gpu_steps_per_s": stats["steps"] / (kernel_ms * 1e-3),
+                       "capped_rays": stats["capped"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "algorithmic bytes; the kernel is fp64-VALU/latency "
+                                 "shaped, see DESIGN.md"},
+            "tally": {"hits": [int(v) for v in tally[: n_media + 1].tolist()]},
+        }
+        if not args.no_cpu and world == 1:
+            cpu, cores, _ = cpu_baseline(nodes, args.cpu_rays, 0x5EED2026)
+            line["cpu_baseline"] = {
+                "value": cpu["range0"], "unit": "ray-steps/s", "cores": cores,
+                "kind": "port",
+                "sample": f"{args.cpu_rays} rays of the same recipe, oracle/ C restatement, "
+                          f"{cores} pthreads, exact transform (range 0); "
+                          f"range 1: {cpu['range1']:.4g} steps/s; "
+                          f"one core: {cpu['one_core']:.4g} steps/s"}
+        print(json.dumps(line), flush=True)
+
+    stepper.destroy()
+    tile.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

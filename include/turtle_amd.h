@@ -1,0 +1,297 @@
+/*
+ * turtle_amd.h -- C ABI of libturtle_amd.so, an MI355X-native implementation
+ * of TURTLE's optimistic ray/terrain stepper path.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) DROP-IN: the reference's own public functions for this path, with the
+ *      same names, argument meaning, ownership and error convention, so that a
+ *      caller written against the reference's `turtle.h` links unchanged
+ *      (`#include "turtle.h"` from this directory forwards here).  Each
+ *      declaration cites the reference declaration it replaces as
+ *      [ref include/turtle.h:LINE] and the implementation it restates as
+ *      [impl src/turtle/FILE.c:LINE] (paths under the reference tree).
+ *      These are scalar calls: each one runs the same device kernels as the
+ *      batch form with n = 1 and therefore costs one kernel launch.  There is
+ *      NO CPU implementation of the arithmetic in this library; without a
+ *      usable gfx950 device every computing entry point fails with
+ *      TURTLE_RETURN_LIBRARY_ERROR through the error handler.
+ *
+ *  (2) BATCH EXTENSION (suffix _n, prefix turtle_amd_): the same operations on
+ *      n independent rays/points per call, which is what a GPU is for.  The
+ *      reference has no such entry points; INTEGRATION.md shows the few lines
+ *      a maintainer adds to bind them.  Arrays are plain C arrays, one element
+ *      (or one double[3] / double[2] / int[2] group) per ray, in HOST or DEVICE
+ *      memory according to `space`.
+ *
+ * Units and conventions are the reference's: degrees, metres, WGS84 ECEF.
+ */
+#ifndef TURTLE_AMD_H
+#define TURTLE_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef TURTLE_API
+#define TURTLE_API
+#endif
+
+/* ---- return codes and handles [ref include/turtle.h:35-62, :64-106] ---- */
+enum turtle_return {
+        TURTLE_RETURN_SUCCESS = 0,
+        TURTLE_RETURN_BAD_ADDRESS,
+        TURTLE_RETURN_BAD_EXTENSION,
+        TURTLE_RETURN_BAD_FORMAT,
+        TURTLE_RETURN_BAD_PROJECTION,
+        TURTLE_RETURN_BAD_JSON,
+        TURTLE_RETURN_DOMAIN_ERROR,
+        TURTLE_RETURN_LIBRARY_ERROR,
+        TURTLE_RETURN_LOCK_ERROR,
+        TURTLE_RETURN_MEMORY_ERROR,
+        TURTLE_RETURN_PATH_ERROR,
+        TURTLE_RETURN_UNLOCK_ERROR,
+        N_TURTLE_RETURNS
+};
+
+struct turtle_projection; /* opaque; projected maps are not on this path yet */
+struct turtle_map;
+struct turtle_stack;
+struct turtle_client;
+struct turtle_stepper;
+
+/* [ref include/turtle.h:93-106] */
+struct turtle_map_info {
+        int nx, ny;           /* nodes along x and y */
+        double x[2];          /* x range (longitude for geodetic maps) */
+        double y[2];          /* y range (latitude) */
+        double z[2];          /* elevation range spanned by the 16-bit code */
+        const char * encoding;
+};
+
+/* ---- error handling [ref include/turtle.h:114-194; impl error.c:28-198] ----
+ * Every enum-returning function returns TURTLE_RETURN_SUCCESS or a code and,
+ * unless the handler is NULL, calls the handler once with a message shaped
+ * "{ <function> [#<code>], <file>:<line> } <text>".  The default handler prints
+ * the message to stderr and exit(EXIT_FAILURE)s, as the reference's does. */
+typedef void turtle_function_t(void);
+typedef void turtle_error_handler_t(enum turtle_return code,
+    turtle_function_t * function, const char * message);
+typedef int turtle_stack_locker_t(void); /* [ref include/turtle.h:149] */
+
+TURTLE_API const char * turtle_error_function(turtle_function_t * function);
+TURTLE_API turtle_error_handler_t * turtle_error_handler_get(void);
+TURTLE_API void turtle_error_handler_set(turtle_error_handler_t * handler);
+
+/* ---- ECEF transforms [ref include/turtle.h:556-602; impl ecef.c:41-207] ---- */
+TURTLE_API void turtle_ecef_from_geodetic(
+    double latitude, double longitude, double elevation, double ecef[3]);
+TURTLE_API void turtle_ecef_to_geodetic(const double ecef[3], double * latitude,
+    double * longitude, double * altitude);
+TURTLE_API void turtle_ecef_from_horizontal(double latitude, double longitude,
+    double azimuth, double elevation, double direction[3]);
+TURTLE_API void turtle_ecef_to_horizontal(double latitude, double longitude,
+    const double direction[3], double * azimuth, double * elevation);
+
+/* ---- maps [ref include/turtle.h:362-543; impl map.c:54-421] ----
+ * `projection` must be NULL (geodetic grid): projected maps are the next row
+ * of the scope table and return TURTLE_RETURN_BAD_PROJECTION for now.
+ * turtle_map_load reads .hgt tiles [impl io/hgt.c:45-151]; other extensions
+ * return TURTLE_RETURN_BAD_EXTENSION. */
+TURTLE_API enum turtle_return turtle_map_create(struct turtle_map ** map,
+    const struct turtle_map_info * info, const char * projection);
+TURTLE_API void turtle_map_destroy(struct turtle_map ** map);
+TURTLE_API enum turtle_return turtle_map_load(
+    struct turtle_map ** map, const char * path);
+TURTLE_API enum turtle_return turtle_map_fill(
+    struct turtle_map * map, int ix, int iy, double elevation);
+TURTLE_API enum turtle_return turtle_map_node(const struct turtle_map * map,
+    int ix, int iy, double * x, double * y, double * elevation);
+TURTLE_API enum turtle_return turtle_map_elevation(
+    const struct turtle_map * map, double x, double y, double * elevation,
+    int * inside);
+TURTLE_API const struct turtle_projection * turtle_map_projection(
+    const struct turtle_map * map);
+TURTLE_API void turtle_map_meta(const struct turtle_map * map,
+    struct turtle_map_info * info, const char ** projection);
+
+/* ---- tile stacks [ref include/turtle.h:637-719; impl stack.c:46-450] ----
+ * All tiles a stack loads become resident in HBM (288 GB holds any of the
+ * configurations; `stack_size` is recorded and bounds the HOST-side copies
+ * only).  Lookup semantics are the reference's with every tile loaded:
+ * half-open tile boxes, exclusive outer upper edge, missing tile => inside=0. */
+TURTLE_API enum turtle_return turtle_stack_create(struct turtle_stack ** stack,
+    const char * path, int stack_size, turtle_stack_locker_t * lock,
+    turtle_stack_locker_t * unlock);
+TURTLE_API void turtle_stack_destroy(struct turtle_stack ** stack);
+TURTLE_API enum turtle_return turtle_stack_clear(struct turtle_stack * stack);
+TURTLE_API enum turtle_return turtle_stack_load(struct turtle_stack * stack);
+TURTLE_API enum turtle_return turtle_stack_elevation(
+    struct turtle_stack * stack, double latitude, double longitude,
+    double * elevation, int * inside);
+
+/* ---- clients [ref include/turtle.h:773-842; impl client.c:41-188] ----
+ * Same answers as the stack; the reference's per-thread tile pinning has no
+ * device analogue and is not reproduced. */
+TURTLE_API enum turtle_return turtle_client_create(
+    struct turtle_client ** client, struct turtle_stack * stack);
+TURTLE_API enum turtle_return turtle_client_destroy(
+    struct turtle_client ** client);
+TURTLE_API enum turtle_return turtle_client_clear(
+    struct turtle_client * client);
+TURTLE_API enum turtle_return turtle_client_elevation(
+    struct turtle_client * client, double latitude, double longitude,
+    double * elevation, int * inside);
+
+/* ---- stepper [ref include/turtle.h:859-1155; impl stepper.c:379-931] ---- */
+TURTLE_API enum turtle_return turtle_stepper_create(
+    struct turtle_stepper ** stepper);
+TURTLE_API enum turtle_return turtle_stepper_destroy(
+    struct turtle_stepper ** stepper);
+TURTLE_API void turtle_stepper_geoid_set(
+    struct turtle_stepper * stepper, struct turtle_map * geoid);
+TURTLE_API struct turtle_map * turtle_stepper_geoid_get(
+    const struct turtle_stepper * stepper);
+TURTLE_API void turtle_stepper_reset(struct turtle_stepper * stepper);
+/* The local-linear-approximation range [impl stepper.c:85-171] is stored and
+ * returned for compatibility; the device always uses the exact transform,
+ * i.e. behaves as the reference does at range 0 (difference at the default
+ * range 1: 1.5e-9 relative on path length). */
+TURTLE_API void turtle_stepper_range_set(
+    struct turtle_stepper * stepper, double range);
+TURTLE_API double turtle_stepper_range_get(
+    const struct turtle_stepper * stepper);
+TURTLE_API double turtle_stepper_slope_get(
+    const struct turtle_stepper * stepper);
+TURTLE_API void turtle_stepper_slope_set(
+    struct turtle_stepper * stepper, double slope);
+TURTLE_API double turtle_stepper_resolution_get(
+    const struct turtle_stepper * stepper);
+TURTLE_API void turtle_stepper_resolution_set(
+    struct turtle_stepper * stepper, double resolution);
+TURTLE_API enum turtle_return turtle_stepper_add_layer(
+    struct turtle_stepper * stepper);
+TURTLE_API enum turtle_return turtle_stepper_add_stack(
+    struct turtle_stepper * stepper, struct turtle_stack * stack,
+    double offset);
+TURTLE_API enum turtle_return turtle_stepper_add_map(
+    struct turtle_stepper * stepper, struct turtle_map * map, double offset);
+TURTLE_API enum turtle_return turtle_stepper_add_flat(
+    struct turtle_stepper * stepper, double ground_level);
+/* [ref include/turtle.h:1126-1129; impl stepper.c:780-875] */
+TURTLE_API enum turtle_return turtle_stepper_step(
+    struct turtle_stepper * stepper, double * position,
+    const double * direction, double * latitude, double * longitude,
+    double * altitude, double * elevation, double * step, int * index);
+/* [ref include/turtle.h:1153-1155; impl stepper.c:877-931] */
+TURTLE_API enum turtle_return turtle_stepper_position(
+    struct turtle_stepper * stepper, double latitude, double longitude,
+    double height, int layer_index, double * position, int * data_index);
+
+/* ======================================================================== */
+/*                    BATCH EXTENSION (not in the reference)                */
+/* ======================================================================== */
+
+/* Where the arrays of a batch call live. */
+enum turtle_amd_space {
+        TURTLE_AMD_HOST = 0,  /* host pointers: copied in/out, call is synchronous */
+        TURTLE_AMD_DEVICE = 1 /* device pointers on the selected GPU: the call
+                                 only enqueues work on the library stream */
+};
+
+/* Device / stream management.  One process drives one GPU (one process per
+ * GPU is the multi-GPU model).  The default device is
+ * $LOCAL_RANK if set, else 0. */
+TURTLE_API int turtle_amd_device_count(void);
+TURTLE_API enum turtle_return turtle_amd_device_set(int device);
+TURTLE_API int turtle_amd_device_get(void);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream) for every
+ * subsequent launch; NULL restores the library's own stream. */
+TURTLE_API enum turtle_return turtle_amd_stream_set(void * hip_stream);
+TURTLE_API enum turtle_return turtle_amd_synchronize(void);
+/* Number of compute units of the selected device (0 if none). */
+TURTLE_API int turtle_amd_compute_units(void);
+
+/* n independent ECEF transforms; same arithmetic as the scalar forms. */
+TURTLE_API enum turtle_return turtle_ecef_from_geodetic_n(long n,
+    const double * latitude, const double * longitude,
+    const double * elevation, double * ecef /* [n][3] */, int space);
+TURTLE_API enum turtle_return turtle_ecef_to_geodetic_n(long n,
+    const double * ecef /* [n][3] */, double * latitude, double * longitude,
+    double * altitude, int space);
+TURTLE_API enum turtle_return turtle_ecef_from_horizontal_n(long n,
+    const double * latitude, const double * longitude, const double * azimuth,
+    const double * elevation, double * direction /* [n][3] */, int space);
+TURTLE_API enum turtle_return turtle_ecef_to_horizontal_n(long n,
+    const double * latitude, const double * longitude,
+    const double * direction /* [n][3] */, double * azimuth,
+    double * elevation, int space);
+
+/* n bilinear lookups.  `inside` is mandatory (a point outside the data is
+ * reported there, never raised). */
+TURTLE_API enum turtle_return turtle_map_elevation_n(
+    const struct turtle_map * map, long n, const double * x, const double * y,
+    double * elevation, int * inside, int space);
+TURTLE_API enum turtle_return turtle_stack_elevation_n(
+    struct turtle_stack * stack, long n, const double * latitude,
+    const double * longitude, double * elevation, int * inside, int space);
+
+/* n calls of turtle_stepper_position; `position` rows of rays with no data
+ * are left untouched and their data_index is -1 (data_index is mandatory). */
+TURTLE_API enum turtle_return turtle_stepper_position_n(
+    struct turtle_stepper * stepper, long n, const double * latitude,
+    const double * longitude, const double * height, int layer_index,
+    double * position /* [n][3] */, int * data_index, int space);
+
+/* Flags of turtle_stepper_step_n. */
+enum turtle_amd_step_flags {
+        /* On entry altitude[], elevation[][2] and index[][2] hold the values a
+         * previous call returned for the SAME positions: skip the sample at
+         * the start point, exactly as the reference's `last` cache does when
+         * the position is unchanged [impl stepper.c:708-710, :745-748]. */
+        TURTLE_AMD_STEP_RESUME = 1
+};
+
+/* n independent turtle_stepper_step calls.  `direction` may be NULL (sample
+ * only; step[] is the tentative length).  Every output array may be NULL
+ * except index, which is mandatory: leaving the data is reported as
+ * index[r][0] = -1, never raised.  position is updated in place. */
+TURTLE_API enum turtle_return turtle_stepper_step_n(
+    struct turtle_stepper * stepper, long n, double * position /* [n][3] */,
+    const double * direction /* [n][3] or NULL */, double * latitude,
+    double * longitude, double * altitude, double * elevation /* [n][2] */,
+    double * step, int * index /* [n][2] */, int flags, int space);
+
+/* The per-ray loop of a Monte-Carlo harness, moved into one kernel: for each
+ * ray sample its start point, then step until index[0] differs from its
+ * initial value (a boundary was located) or max_steps steps were taken
+ * [shape of examples/example-stepper.c:128-140].  Outputs per ray: final
+ * index pair, path length = sum of the step lengths, number of steps; the
+ * position is advanced in place.  Rays that start outside the data take 0
+ * steps and report index[0] = -1.  length/n_steps may be NULL. */
+TURTLE_API enum turtle_return turtle_stepper_trace_n(
+    struct turtle_stepper * stepper, long n, double * position /* [n][3] */,
+    const double * direction /* [n][3] */, int max_steps,
+    int * index /* [n][2] */, double * length, int * n_steps, int space);
+
+/* Totals of the LAST trace_n call on this stepper, accumulated on the device:
+ * stats[0] rays, [1] steps, [2] samples (transform + layer lookup), [3]
+ * rays that stopped at max_steps.  Synchronises the stream. */
+TURTLE_API enum turtle_return turtle_stepper_trace_stats(
+    struct turtle_stepper * stepper, unsigned long long stats[4]);
+
+/* Reduce trace results for a multi-GPU tally: hits[m + 1] counts
+ * rays whose final index[0] == m, for m in [-1, n_media); histogram[b] counts
+ * path lengths in bin b of n_bins linear bins over [0, length_max), the last
+ * extra bin (histogram[n_bins]) collecting overflows.  Both are uint64 and are
+ * ADDED to, so ranks can accumulate and then all-reduce them. */
+TURTLE_API enum turtle_return turtle_amd_tally_n(long n,
+    const int * index /* [n][2] */, const double * length, int n_media,
+    unsigned long long * hits /* [n_media + 1] */, int n_bins,
+    double length_max, unsigned long long * histogram /* [n_bins + 1] */,
+    int space);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

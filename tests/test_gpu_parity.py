@@ -1,0 +1,368 @@
+"""Parity of the HIP path (through the C ABI) with the reference.
+
+Three checkers, in decreasing authority:
+  * tests/golden/*.npz -- outputs of the real reference on stored inputs;
+  * the CPU restatement (oracle/), itself pinned bit-for-bit to those;
+  * size-independent properties at the BASELINE sizes (test_gpu_properties).
+
+Bar (BASELINE.json north_star): identical medium index, path length within
+1e-6 relative.  Integer/byte work (node decode, tile selection, inside flags)
+is bit-exact.  Transcendentals come from OCML instead of glibc, so floating
+outputs may differ in the last ulp: tolerances are written at each assert.
+"""
+import numpy as np
+import pytest
+
+import turtle_amd as TA
+from oracle import ffi as O
+
+import amd_build as B
+import terrains as T
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6  # the parity bar on path length
+
+
+def check_trace(t, ref_index, ref_length, ref_nsteps, what, allow=0):
+    """identical medium; |dL|/L <= 1e-6; report grazing mismatches."""
+    idx = np.asarray(t["index"])
+    bad = np.flatnonzero((idx[:, 0] != ref_index[:, 0]))
+    assert bad.size <= allow, f"{what}: {bad.size} rays changed medium: {bad[:10]}"
+    ok = np.ones(idx.shape[0], dtype=bool)
+    ok[bad] = False
+    L, L0 = np.asarray(t["length"])[ok], ref_length[ok]
+    rel = np.abs(L - L0) / np.maximum(np.abs(L0), 1e-300)
+    rel[L0 == 0] = np.abs(L[L0 == 0])
+    assert rel.max() <= REL, f"{what}: path length off by {rel.max():.3e}"
+    # data index and step count: equal except where a last-ulp difference
+    # moves a sample across a cell edge or a bisection bracket by one
+    ds = np.abs(np.asarray(t["n_steps"])[ok] - ref_nsteps[ok])
+    assert (ds <= 1).all() and (ds != 0).mean() < 1e-2, f"{what}: step counts differ"
+    return rel.max()
+
+
+def test_ecef_known_answers(golden):
+    g = golden("ecef")
+    e = TA.ecef_from_geodetic(g["lat"], g["lon"], g["alt"])
+    # sin/cos of OCML vs glibc: 1-2 ulp of 6.4e6 m
+    assert np.abs(e - g["ecef"]).max() < 5e-9
+    la, lo, al = TA.ecef_to_geodetic(g["ecef_all"])
+    assert np.abs(la - g["to_lat"]).max() < 1e-13 * 90
+    assert np.abs(lo - g["to_lon"]).max() < 1e-13 * 180
+    assert np.abs(al - g["to_alt"]).max() < 5e-9
+    # exact special cases [ref ecef.c:77-84]: the last rows of ecef_all
+    assert la[-7] == 90.0 and lo[-7] == 0.0 and la[-6] == -90.0
+    assert al[-7] == g["to_alt"][-7] and al[-5] == g["to_alt"][-5]
+    d = TA.ecef_from_horizontal(g["lat"], g["lon"], g["az"], g["el"])
+    assert np.abs(d - g["direction"]).max() < 1e-15 * 4
+    az, el = TA.ecef_to_horizontal(g["lat"], g["lon"], g["dir_scaled"])
+    daz = np.abs(az - g["to_az"])
+    daz = np.minimum(daz, 360 - daz)
+    # azimuth is ill-conditioned near the zenith/nadir: scale by 1/cos(el)
+    assert (daz * np.cos(np.radians(g["to_el"])) < 1e-11).all()
+    # asin near +-1 amplifies an ulp of its argument by 1/cos(el)
+    assert (np.abs(el - g["to_el"]) * np.maximum(np.cos(np.radians(g["to_el"])), 1e-8)
+            < 1e-11).all()
+    assert az[5] == 0.0 and el[5] == 0.0  # null direction: untouched
+
+
+def test_ecef_reference_assertions():
+    """tests/test-turtle.c:582-625 through the SCALAR drop-in calls."""
+    from turtle_amd import binding as Bn
+    p = Bn.scalar_ecef_from_geodetic(45.5, 3.5, 1000.0)
+    la, lo, al = Bn.scalar_ecef_to_geodetic(p)
+    assert abs(la - 45.5) < 1e-8 and abs(lo - 3.5) < 1e-8 and abs(al - 1000) < 1e-8
+    la, lo, al = Bn.scalar_ecef_to_geodetic([0.0, 0.0, 6356752.3142 + 1000.0])
+    assert la == 90.0 and lo == 0.0 and abs(al - 1000.0) < 1e-9
+    p = Bn.scalar_ecef_from_geodetic(0.0, 90.0, 1000.0)
+    la, lo, al = Bn.scalar_ecef_to_geodetic(p)
+    assert la == 0.0 and lo == 90.0 and abs(al - 1000) < 1e-8
+
+
+def test_bilinear_bit_exact(golden):
+    g = golden("bilinear")
+    m = B.c1_map()
+    z, inside = m.elevation(g["x"], g["y"])
+    assert np.array_equal(inside, g["inside"])
+    ok = inside == 1
+    assert np.array_equal(z[ok], g["z"][ok])  # +,-,*,/ only: bit-exact
+    for ix, iy, xyz in zip(g["node_ix"], g["node_iy"], g["node_xyz"]):
+        assert m.node(int(ix), int(iy)) == tuple(xyz)
+    # scalar drop-in: outside leaves *elevation untouched; inside==NULL raises
+    zz, ii = m.elevation_scalar(3.5, 45.5)
+    k = 0
+    assert ii == 1
+    zz, ii = m.elevation_scalar(2.0, 45.5)
+    assert ii == 0 and zz == -12345.0
+    with pytest.raises(TA.TurtleError) as e:
+        m.elevation_scalar(2.0, 45.5, want_inside=False)
+    assert e.value.name == "DOMAIN_ERROR" and "point is outside of map" in str(e.value)
+    m.destroy()
+
+
+def test_c1_traces(golden):
+    g = golden("c1_traces")
+    m = B.c1_map()
+    st = B.c1_stepper(m)
+    pos, di = st.position(g["lat"], g["lon"], 500.0)
+    assert (di == 0).all() and np.abs(pos - g["position"]).max() < 5e-9
+    t = st.trace(g["position"].copy(), g["direction"])
+    check_trace(t, g["r0_index"], g["r0_length"], g["r0_n_steps"], "C1 vs reference range=0")
+    # the reference's default (local_range = 1) differs from it by ~1e-9 only
+    check_trace(t, g["r1_index"], g["r1_length"], g["r1_n_steps"], "C1 vs reference range=1")
+    assert np.abs(t["position"] - g["r0_position"]).max() < 1e-5
+    s = st.trace_stats()
+    assert s["rays"] == 1000 and s["steps"] == int(np.sum(t["n_steps"])) and s["capped"] == 0
+    assert 1.0 < s["samples"] / s["steps"] < 1.2  # ~1.05 samples per step
+    st.destroy()
+    m.destroy()
+
+
+def test_c1_per_step_records(golden):
+    """G7: every step of 16 rays (position, ds, index) against the reference."""
+    g = golden("steps")
+    m = B.c1_map()
+    st = B.c1_stepper(m)
+    rec = g["record"]
+    pos = g["position"].copy()
+    direction = g["direction"]
+    alive = np.ones(16, dtype=bool)
+    for k in range(1, int(rec[:, 1].max()) + 1):
+        rows = rec[rec[:, 1] == k]
+        rays = rows[:, 0].astype(int)
+        o = st.step(pos[rays].copy(), direction[rays])
+        assert np.array_equal(o["index"], rows[:, 6:8].astype(np.int32))
+        assert np.abs(o["step"] - rows[:, 5]).max() <= 1e-6 * np.abs(rows[:, 5]).max()
+        assert np.abs(o["position"] - rows[:, 2:5]).max() < 1e-5
+        pos[rays] = o["position"]
+    st.destroy()
+    m.destroy()
+
+
+def test_hgt_tile_traces(golden, tmp_path):
+    g = golden("hgt_traces")
+    m = B.hgt_tile(tmp_path)
+    for ix, iy, z in zip(g["node_ix"][:64], g["node_iy"][:64], g["node_z"][:64]):
+        assert m.node(int(ix), int(iy))[2] == z
+    z, inside = m.elevation(g["qx"], g["qy"])
+    assert np.array_equal(inside, g["qin"])
+    assert np.array_equal(z[inside == 1], g["qz"][inside == 1])
+    st = TA.Stepper()
+    st.add_map(m, 0.0)
+    pos, di = st.position(g["lat"], g["lon"], 500.0)
+    assert np.abs(pos - g["position"]).max() < 5e-9
+    t = st.trace(g["position"].copy(), g["direction"])
+    worst = check_trace(t, g["r0_index"], g["r0_length"], g["r0_n_steps"],
+                        "3601^2 tile vs reference", allow=2)
+    print(f"hgt 10k rays: worst relative path-length difference {worst:.2e}")
+    st.destroy()
+    m.destroy()
+
+
+def test_stack_directory(golden, tmp_path):
+    g = golden("stack")
+    n = int(g["n"])
+    stack = B.mosaic(tmp_path, [tuple(t) for t in g["tiles"]], n)
+    z, inside = stack.elevation(g["lat"], g["lon"])
+    assert np.array_equal(inside, g["inside"])
+    assert np.array_equal(z, g["z"])  # bit-exact, incl. 0 for outside/missing
+    # scalar drop-in: missing tile with inside==NULL raises PATH_ERROR
+    zz, ii = stack.elevation_scalar(46.5, 4.5)
+    assert ii == 0 and zz == 0.0
+    with pytest.raises(TA.TurtleError) as e:
+        stack.elevation_scalar(46.5, 4.5, want_inside=False)
+    assert e.value.name == "PATH_ERROR" and "missing elevation data" in str(e.value)
+    st = TA.Stepper()
+    st.add_stack(stack, 0.0)
+    pos, di = st.position(g["ray_lat"], g["ray_lon"], 300.0)
+    assert (di == 0).all() and np.abs(pos - g["position"]).max() < 5e-9
+    t = st.trace(g["position"].copy(), g["direction"])
+    check_trace(t, g["t_index"], g["t_length"], g["t_n_steps"], "2x2 mosaic", allow=1)
+    st.destroy()
+    stack.destroy()
+    one = B.mosaic(tmp_path / "one", [(45, 3)], n)
+    z1, in1 = one.elevation(g["lat1"], g["lon1"])
+    assert np.array_equal(in1, g["in1"]) and np.array_equal(z1, g["z1"])
+    one.destroy()
+
+
+@pytest.mark.parametrize("name", ["nogeoid", "geoid"])
+def test_layers_offsets_flat_geoid(golden, name):
+    g = golden("layers")
+    m = B.c1_map()
+    geoid = B.geoid_map(g["geoid_nodes"]) if name == "geoid" else None
+    st = B.two_layer_stepper(m, geoid)
+    P, D, Oq = g[name + "_P"], g[name + "_D"], g[name + "_O"]
+    for slope in (0.4, 2.0):
+        st.slope = slope
+        for has_dir in (0, 1):
+            sel = (Oq[:, 2] == slope) & (Oq[:, 1] == has_dir)
+            ref = Oq[sel]
+            o = st.step(P[sel].copy(), D[sel] if has_dir else None)
+            assert np.array_equal(o["index"], ref[:, 12:14].astype(np.int32))
+            assert np.abs(o["latitude"] - ref[:, 6]).max() < 1e-11
+            assert np.abs(o["longitude"] - ref[:, 7]).max() < 1e-11
+            assert np.abs(o["altitude"] - ref[:, 8]).max() < 5e-9
+            e = o["elevation"]
+            big = np.abs(ref[:, 9:11]) > 1e300  # +-DBL_MAX sentinels: exact
+            assert np.array_equal(e[big], ref[:, 9:11][big])
+            assert np.abs(e[~big] - ref[:, 9:11][~big]).max() < 1e-9
+            tol = np.maximum(1e-6 * np.abs(ref[:, 11]), 2e-8)  # bisection stops at 1e-8
+            assert (np.abs(o["step"] - ref[:, 11]) <= tol).all()
+            assert np.abs(o["position"] - ref[:, 3:6]).max() < 1e-7
+    st.slope = 0.4
+    t = st.trace(g[name + "_tpos"].copy(), g[name + "_tdir"])
+    check_trace(t, g[name + "_t_index"], g[name + "_t_length"], g[name + "_t_n_steps"],
+                f"two layers ({name})")
+    t2 = st.trace(g[name + "_t_position"].copy(), g[name + "_tdir"])
+    check_trace(t2, g[name + "_t2_index"], g[name + "_t2_length"], g[name + "_t2_n_steps"],
+                f"two layers, second medium ({name})")
+    st.destroy()
+    m.destroy()
+    if geoid is not None:
+        geoid.destroy()
+
+
+def test_reference_stepper_layer_assertions():
+    """tests/test-turtle.c:255-409 re-expressed with geodetic data, through the
+    SCALAR drop-in entry points (turtle_stepper_step / _position)."""
+    DBL_MAX = np.finfo(np.float64).max
+    FLT_EPSILON = float(np.finfo(np.float32).eps)
+    m = B.c1_map()
+    st = B.two_layer_stepper(m)
+    lat0, lon0 = 45.756546, 3.4485671
+    values = np.zeros((2, 2))
+    for i in range(2):
+        p, di = st.position_scalar(lat0, lon0, -0.25, i)
+        assert di == 0
+        o = st.step_scalar(p, None)
+        assert o["index"][0] == i and o["index"][1] == 0
+        values[0][i] = o["altitude"]
+        p, di = st.position_scalar(40.0, 10.0, -0.25, i)
+        assert di == 1  # only the flat data holds that point
+        o = st.step_scalar(p, None)
+        assert o["index"][0] == i and o["index"][1] == 1
+        values[1][i] = o["altitude"]
+    off = (-0.5, 0.0)
+    for i in range(2):
+        assert abs((values[i][0] - off[0]) - (values[i][1] - off[1])) < FLT_EPSILON
+    slope = st.slope
+    assert slope == 0.4 and st.resolution == 1e-2 and st.range == 1.0
+    p, di = st.position_scalar(lat0, lon0, 0.5, 1)
+    o = st.step_scalar(p, None)  # above the top layer
+    assert o["index"][0] == 2 and o["elevation"][1] == DBL_MAX
+    assert abs(o["elevation"][0] - (values[0][1] + 0.25)) < FLT_EPSILON
+    assert abs(o["step"] - 0.5 * slope) < FLT_EPSILON
+    p, di = st.position_scalar(lat0, lon0, -0.1, 1)
+    o = st.step_scalar(p, None)  # between the two surfaces
+    assert list(o["index"]) == [1, 0]
+    assert abs(o["elevation"][0] - (values[0][0] + 0.25)) < FLT_EPSILON
+    assert abs(o["elevation"][1] - (values[0][1] + 0.25)) < FLT_EPSILON
+    assert abs(o["step"] - 0.1 * slope) < FLT_EPSILON
+    p, di = st.position_scalar(lat0, lon0, -0.5, 0)
+    o = st.step_scalar(p, None)  # below everything
+    assert list(o["index"]) == [0, 0] and o["elevation"][0] == -DBL_MAX
+    assert abs(o["step"] - 0.5 * slope) < FLT_EPSILON
+    # boundary location: vertical ray from 0.1 m below the top surface
+    p, di = st.position_scalar(lat0, lon0, -0.1, 1)
+    up = TA.ecef_from_horizontal([lat0], [lon0], [0.0], [90.0])[0]
+    st.slope = 2.0
+    o = st.step_scalar(p, up)
+    assert list(o["index"]) == [2, 0]
+    assert abs(o["altitude"] - (values[0][1] + 0.25)) < 1e-5 and abs(o["step"] - 0.1) < 1e-5
+    o2 = st.step_scalar(o["position"], up)  # next step from the boundary
+    assert list(o2["index"]) == [2, 0] and abs(o2["step"] - st.resolution) < 1e-5
+    # idempotent sampling: two dir=NULL calls are bit-identical [ref :822-838]
+    a, b = st.step_scalar(p, None), st.step_scalar(p, None)
+    for k in ("latitude", "longitude", "altitude", "step"):
+        assert a[k] == b[k]
+    assert np.array_equal(a["elevation"], b["elevation"])
+    st.destroy()
+    m.destroy()
+
+
+def test_reference_stepper_exit_and_outside(tmp_path):
+    """tests/test-turtle.c:852-858, :872-883, :923-931 re-expressed."""
+    m = B.c1_map()
+    st = TA.Stepper()
+    st.add_map(m, 0.0)
+    p, di = st.position_scalar(45.0, 90.0, 0.0, 0, initial=(1.0, 2.0, 3.0))
+    assert di == -1 and list(p) == [1.0, 2.0, 3.0]  # untouched
+    with pytest.raises(TA.TurtleError) as e:
+        st.position_scalar(45.0, 90.0, 0.0, 0, want_index=False)
+    assert e.value.name == "DOMAIN_ERROR" and "no valid data" in str(e.value)
+    with pytest.raises(TA.TurtleError):
+        st.position_scalar(45.5, 3.5, 0.0, 3)  # no such layer
+    # horizontal ray leaves the map in < 100000 steps with index[0] < 0
+    p, di = st.position_scalar(45.5, 3.5, -0.5, 0)
+    d = TA.ecef_from_horizontal([45.5], [3.5], [0.0], [0.0])[0]
+    t = st.trace(p[None, :].copy(), d[None, :], max_steps=100000)
+    assert t["index"][0, 0] == 1  # first it surfaces (medium 0 -> 1)
+    t = st.trace(t["position"], d[None, :], max_steps=100000)
+    assert t["index"][0, 0] == -1 and t["n_steps"][0] < 100000
+    # far away: index = {-1, -1}, elevation = {0, 0}, step 0
+    far = t["position"][0] + d * 1e6
+    o = st.step_scalar(far, None)
+    assert list(o["index"]) == [-1, -1] and list(o["elevation"]) == [0.0, 0.0]
+    assert o["step"] == 0.0
+    with pytest.raises(TA.TurtleError) as e:
+        st.step_scalar(far, None, want_index=False)
+    assert e.value.name == "DOMAIN_ERROR"
+    st.destroy()
+    m.destroy()
+
+
+def test_resume_flag_matches_fresh_sample():
+    m = B.c1_map()
+    st = B.c1_stepper(m)
+    lat, lon, az, el = TA.synth.uniform_rays(512, T.C1_Y, T.C1_X, seed=11)
+    pos, _ = st.position(lat, lon, 400.0)
+    d = TA.ecef_from_horizontal(lat, lon, az, el)
+    a = st.step(pos.copy(), None)            # sample only
+    b = st.step(pos.copy(), d)               # fresh: samples the start itself
+    c = st.step(pos.copy(), d, resume=a)     # resumes from the returned sample
+    for k in ("position", "altitude", "elevation", "index", "step"):
+        assert np.array_equal(np.asarray(b[k]), np.asarray(c[k])), k
+    st.destroy()
+    m.destroy()
+
+
+def test_tally_exact():
+    rng = np.random.default_rng(5)
+    n = 100000
+    index = np.stack([rng.integers(-1, 3, n), np.zeros(n, dtype=np.int64)], 1).astype(np.int32)
+    length = rng.uniform(0, 70000, n)
+    length[:5] = [0.0, 65536.0, 65535.999, np.nan, -1.0]
+    hits, hist = TA.tally(index, length, 3, 1024, 65536.0)
+    assert np.array_equal(hits, np.bincount(index[:, 0] + 1, minlength=4))
+    t = length * (1024 / 65536.0)
+    b = np.full(n, 1024)
+    okk = (t >= 0) & (t < 1024)
+    b[okk] = t[okk].astype(np.int64)
+    assert np.array_equal(hist, np.bincount(b, minlength=1025))
+    hits2, hist2 = TA.tally(index, length, 3, 1024, 65536.0, hits, hist)  # accumulates
+    assert hits2.sum() == 2 * n and hist2.sum() == 2 * n
+
+
+def test_oracle_agrees_on_fresh_rays():
+    """Seeded rays that are NOT in the fixtures: GPU vs the CPU restatement."""
+    geo = T.c1_oracle()
+    m = B.c1_map()
+    st = B.c1_stepper(m)
+    lat, lon, az, el = TA.synth.uniform_rays(4096, T.C1_Y, T.C1_X, seed=77)
+    pos0, _ = geo.position(lat, lon, 500.0)
+    d = O.ecef_from_horizontal(lat, lon, az, el)
+    ref = geo.trace(pos0, d, threads=4)
+    t = st.trace(pos0.copy(), d)
+    check_trace(t, ref["index"], ref["length"], ref["n_steps"], "fresh rays vs oracle", allow=1)
+    # max_steps cap and zero-step edge cases
+    t = st.trace(pos0.copy(), d, max_steps=7)
+    r7 = geo.trace(pos0, d, max_steps=7)
+    assert np.array_equal(t["n_steps"], r7["n_steps"]) and np.array_equal(t["index"], r7["index"])
+    t = st.trace(pos0[:3].copy(), d[:3], max_steps=0)
+    assert (t["n_steps"] == 0).all() and (t["index"][:, 0] == 1).all()
+    e = st.trace(np.zeros((0, 3)), np.zeros((0, 3)))  # empty batch
+    assert e["index"].shape == (0, 2)
+    st.destroy()
+    m.destroy()

@@ -1,0 +1,1061 @@
+/*
+ * device.hip -- the gfx950 device layer of libturtle_amd: HBM management, the
+ * stream, and every kernel of the stepper path.  Written for CDNA4 (wave64);
+ * no other target is supported.
+ *
+ * Arithmetic contract: the kernels evaluate the reference's expressions in
+ * the reference's operand order in IEEE fp64 (this file is compiled with
+ * -ffp-contract=off, so no FMA is formed across the reference's roundings).
+ * +, -, *, / and sqrt are correctly rounded on gfx950, so they agree bit for
+ * bit with the x86 reference; sin/cos/asin/acos/atan2 come from ROCm's OCML
+ * and may differ from glibc in the last ulp, which is the only source of
+ * GPU/CPU differences (<= 1e-9 relative on a path length; the parity bar is
+ * 1e-6).  Citations [ref FILE:LINE] are paths under the reference tree.
+ *
+ * Kernels (one thread = one ray/point; all are fp64 VALU work with a 4-node
+ * 16-bit gather per sample, see DESIGN.md for the roofline of each):
+ *   k_ecef_*        batch ECEF transforms              [ref ecef.c:41-207]
+ *   k_elevation     batch bilinear lookup, map/stack   [ref map.c:229-277, stack.c:300-361]
+ *   k_position      batch turtle_stepper_position      [ref stepper.c:877-931]
+ *   k_step          batch turtle_stepper_step          [ref stepper.c:780-875]
+ *   k_trace         persistent-wave trace-to-boundary loop (the hot kernel)
+ *   k_tally         hit counts + path-length histogram (uint64, exact)
+ */
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "internal.h"
+
+typedef unsigned long long ull;
+
+/* ======================================================================== */
+/*                               device math                                */
+/* ======================================================================== */
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846; /* [ref ecef.c:30-33] */
+constexpr double kA = 6378137;                 /* [ref ecef.c:36-38] */
+constexpr double kB = 6356752.3142;
+constexpr double kE = 0.081819190842622;
+
+/* [ref ecef.c:41-55] */
+__device__ __forceinline__ void d_from_geodetic(
+    double latitude, double longitude, double elevation, double & x, double & y, double & z)
+{
+        const double a = kA, e = kE;
+        const double s = sin(latitude * kPi / 180.);
+        const double c = cos(latitude * kPi / 180.);
+        const double R = a / sqrt(1. - e * e * s * s);
+        x = (R + elevation) * c * cos(longitude * kPi / 180.);
+        y = (R + elevation) * c * sin(longitude * kPi / 180.);
+        z = (R * (1. - e * e) + elevation) * s;
+}
+
+/* [ref ecef.c:63-130] Olson (1996) closed form.  All three outputs are always
+ * produced (the pointer-null shortcuts of the scalar API live on the host). */
+__device__ __forceinline__ void d_to_geodetic(
+    double x, double y, double z, double & latitude, double & longitude, double & altitude)
+{
+        const double a = kA;
+        const double e2 = kE * kE;
+        const double a1 = a * e2;
+        const double a2 = a1 * a1;
+        const double a3 = 0.5 * a1 * e2;
+        const double a4 = 2.5 * a2;
+        const double a5 = a1 + a3;
+        const double a6 = 1. - e2;
+
+        if ((x == 0.) && (y == 0.)) { /* [ref ecef.c:77-84] */
+                latitude = (z >= 0.) ? 90. : -90.;
+                longitude = 0.;
+                altitude = fabs(z) - kB;
+                return;
+        }
+
+        longitude = atan2(y, x) * 180. / kPi;
+
+        const double zp = fabs(z);
+        const double w2 = x * x + y * y;
+        const double w = sqrt(w2);
+        const double z2 = z * z;
+        const double r2 = w2 + z2;
+        const double r = sqrt(r2);
+        const double s2 = z2 / r2;
+        const double c2 = w2 / r2;
+
+        double c, s, ss, la;
+        const double u0 = a2 / r;
+        const double v0 = a3 - a4 / r;
+        if (c2 > 0.3) { /* [ref ecef.c:101-107] */
+                s = (zp / r) * (1. + c2 * (a1 + u0 + s2 * v0) / r);
+                la = asin(s);
+                ss = s * s;
+                c = sqrt(1. - ss);
+        } else { /* [ref ecef.c:108-115] */
+                c = (w / r) * (1. - s2 * (a5 - u0 - c2 * v0) / r);
+                la = acos(c);
+                ss = 1. - c * c;
+                s = sqrt(ss);
+        }
+
+        const double g = 1. - e2 * ss; /* [ref ecef.c:117-129] */
+        const double rg = a / sqrt(g);
+        const double rf = a6 * rg;
+        const double u = w - rg * c;
+        const double v = zp - rf * s;
+        const double f = c * u + s * v;
+        const double m = c * v - s * u;
+        const double p = m / (rf / g + f);
+
+        la += p;
+        if (z < 0.) la = -la;
+        latitude = la * 180. / kPi;
+        altitude = f + 0.5 * m * p;
+}
+
+/* [ref ecef.c:136-154] */
+__device__ __forceinline__ void d_enu(
+    double latitude, double longitude, double e[3], double n[3], double u[3])
+{
+        const double lambda = longitude * kPi / 180.;
+        const double phi = latitude * kPi / 180.;
+        const double sl = sin(lambda), cl = cos(lambda);
+        const double sp = sin(phi), cp = cos(phi);
+        e[0] = -sl, e[1] = cl, e[2] = 0.;
+        n[0] = -cl * sp, n[1] = -sl * sp, n[2] = cp;
+        u[0] = cl * cp, u[1] = sl * cp, u[2] = sp;
+}
+
+/* ---- one grid --------------------------------------------------------- */
+
+__device__ __forceinline__ double d_node(const tamd_grid & g, int ix, int iy)
+{
+        const uint16_t raw = g.nodes[(long)iy * g.nx + ix];
+        const double v = g.is_signed ? (double)(int16_t)raw : (double)raw;
+        return g.z0 + v * g.dz; /* [ref map.c:41-44]; exact for z0=0, dz=1 */
+}
+
+/* [ref map.c:229-277]: inclusive upper edge, truncation toward zero, the
+ * four-term sum in the reference's operand order. */
+__device__ __forceinline__ bool d_grid_elevation(
+    const tamd_grid & g, double x, double y, double & z)
+{
+        if (isnan(x) || isnan(y)) return false; /* [ref map.c:233-240] */
+        double hx = (x - g.x0) / g.dx;
+        double hy = (y - g.y0) / g.dy;
+        if ((hx > g.nx - 1) || (hx < 0) || (hy > g.ny - 1) || (hy < 0))
+                return false; /* [ref map.c:247-255] */
+        int ix = (int)hx;
+        int iy = (int)hy;
+        if (ix == g.nx - 1) { /* [ref map.c:256-265] */
+                ix--;
+                hx = 1.;
+        } else
+                hx -= ix;
+        if (iy == g.ny - 1) {
+                iy--;
+                hy = 1.;
+        } else
+                hy -= iy;
+        const double z00 = d_node(g, ix, iy);
+        const double z10 = d_node(g, ix + 1, iy);
+        const double z01 = d_node(g, ix, iy + 1);
+        const double z11 = d_node(g, ix + 1, iy + 1);
+        z = z00 * (1. - hx) * (1. - hy) + z01 * (1. - hx) * hy +
+            z10 * hx * (1. - hy) + z11 * hx * hy; /* [ref map.c:272-273] */
+        return true;
+}
+
+/* ---- tile directory --------------------------------------------------- */
+
+/* half-open box of a resident tile [ref stack.c:307-311, :320-321] */
+__device__ __forceinline__ bool d_tile_holds(
+    const tamd_grid & g, double latitude, double longitude)
+{
+        const double hx = (longitude - g.x0) / g.dx;
+        const double hy = (latitude - g.y0) / g.dy;
+        return (hx >= 0.) && (hx < g.nx - 1) && (hy >= 0.) && (hy < g.ny - 1);
+}
+
+/* [ref stack.c:338-361] with every tile resident.  The reference scans its
+ * tile list for the one whose half-open box holds the point and only then
+ * falls back on the directory formula of turtle_stack_load_ [ref
+ * stack.c:413-424], applying the inclusive bilinear test to that tile.  Here
+ * the directory formula proposes the tile first (O(1)); its neighbours are
+ * consulted only when rounding at a seam makes the box test disagree, which
+ * reproduces the list scan's answer without the list. */
+__device__ __forceinline__ bool d_stack_elevation(const tamd_view & v,
+    const tamd_stack & st, double latitude, double longitude, double & z)
+{
+        z = 0.;
+        const double fx = (longitude - st.lon0) / st.dlon;
+        const double fy = (latitude - st.lat0) / st.dlat;
+        /* no tile box reaches further than one cell from the directory */
+        if (!((fx > -1.5) && (fx < st.nlon + 1.5) && (fy > -1.5) &&
+                (fy < st.nlat + 1.5)))
+                return false;
+        const int cx = min(max((int)fx, 0), st.nlon - 1);
+        const int cy = min(max((int)fy, 0), st.nlat - 1);
+        const int * tiles = v.tiles + st.tile_first;
+        {
+                const int t = tiles[cy * st.nlon + cx];
+                if ((t >= 0) && d_tile_holds(v.grids[t], latitude, longitude))
+                        return d_grid_elevation(v.grids[t], longitude, latitude, z);
+        }
+        for (int j = -1; j <= 1; j++) {
+                for (int i = -1; i <= 1; i++) {
+                        if ((i == 0) && (j == 0)) continue;
+                        const int ix = cx + i, iy = cy + j;
+                        if ((ix < 0) || (ix >= st.nlon) || (iy < 0) || (iy >= st.nlat))
+                                continue;
+                        const int t = tiles[iy * st.nlon + ix];
+                        if ((t >= 0) && d_tile_holds(v.grids[t], latitude, longitude))
+                                return d_grid_elevation(
+                                    v.grids[t], longitude, latitude, z);
+                }
+        }
+        /* [ref stack.c:413-424] */
+        if ((longitude < st.lon0) || (latitude < st.lat0)) return false;
+        if (!(fx < st.nlon) || !(fy < st.nlat)) return false;
+        const int t = tiles[(int)fy * st.nlon + (int)fx];
+        if (t < 0) return false;
+        const bool inside = d_grid_elevation(v.grids[t], longitude, latitude, z);
+        if (!inside) z = 0.;
+        return inside;
+}
+
+/* ---- layered sample ---------------------------------------------------- */
+
+struct Sample {
+        double lat, lon, alt;
+        double e0, e1; /* bounding elevations [ref stepper.h:93-98] */
+        int m, k;      /* index[0] = medium/layer, index[1] = data */
+};
+
+__device__ __forceinline__ bool d_source_elevation(const tamd_view & v,
+    const tamd_meta & mt, double latitude, double longitude, double & z)
+{
+        if (mt.kind == TAMD_FLAT) { /* [ref stepper.c:252-264] */
+                z = 0.;
+                return true;
+        } else if (mt.kind == TAMD_MAP) { /* [ref stepper.c:240-241] x=lon, y=lat */
+                return d_grid_elevation(v.grids[mt.src], longitude, latitude, z);
+        }
+        return d_stack_elevation(v, v.stacks[mt.src], latitude, longitude, z);
+}
+
+/* [ref stepper.c:703-756] + check_layer [ref stepper.c:687-701], always with
+ * the exact transform (the reference at local_range = 0) and, when a geoid is
+ * set, its undulation removed from the altitude [ref stepper.c:37-51]. */
+template <int MODE>
+__device__ __forceinline__ void d_sample(
+    const tamd_view & v, double x, double y, double z, Sample & s)
+{
+        d_to_geodetic(x, y, z, s.lat, s.lon, s.alt);
+        s.m = -1, s.k = -1;
+        s.e0 = -DBL_MAX, s.e1 = DBL_MAX; /* [ref stepper.c:713-716] */
+
+        if (MODE != TAMD_MODE_GENERIC) {
+                /* one layer holding one data: no loops, no geoid */
+                const tamd_meta mt = v.metas[0];
+                double elevation;
+                const bool inside = (MODE == TAMD_MODE_ONE_MAP) ?
+                    d_grid_elevation(v.grids[mt.src], s.lon, s.lat, elevation) :
+                    d_stack_elevation(v, v.stacks[mt.src], s.lat, s.lon, elevation);
+                if (inside) {
+                        elevation += mt.offset;
+                        s.k = 0;
+                        if (elevation >= s.alt) {
+                                s.m = 0;
+                                s.e1 = elevation;
+                        } else {
+                                s.m = 1;
+                                s.e0 = elevation;
+                        }
+                }
+                return;
+        }
+
+        if (v.geoid >= 0) {
+                double undulation;
+                const double lo = (s.lon >= 0) ? s.lon : s.lon + 360.;
+                if (d_grid_elevation(v.grids[v.geoid], lo, s.lat, undulation))
+                        s.alt -= undulation;
+        }
+        for (int layer = 0; layer < v.n_layers; layer++) {
+                const int end = v.layer_first[layer + 1];
+                int data_index = 0;
+                for (int j = v.layer_first[layer]; j < end; j++, data_index++) {
+                        const tamd_meta mt = v.metas[j];
+                        double elevation;
+                        if (!d_source_elevation(v, mt, s.lat, s.lon, elevation))
+                                continue;
+                        elevation += mt.offset; /* [ref stepper.c:737] */
+                        s.k = data_index;
+                        if (elevation >= s.alt) { /* [ref stepper.c:690-694] */
+                                s.m = layer;
+                                s.e1 = elevation;
+                                return;
+                        }
+                        s.m = layer + 1; /* [ref stepper.c:695-699] */
+                        s.e0 = elevation;
+                        break;
+                }
+        }
+}
+
+/* [ref stepper.c:799-813] tentative step length from the last sample */
+__device__ __forceinline__ double d_step_length(
+    const tamd_view & v, double alt, double e0, double e1, int m)
+{
+        double ds = 0.;
+        if (m != 0) {
+                const double dsi = fabs(alt - e0);
+                if ((dsi < ds) || (ds <= 0.)) ds = dsi;
+        }
+        if (m != v.n_layers) {
+                const double dsi = fabs(alt - e1);
+                if ((dsi < ds) || (ds <= 0.)) ds = dsi;
+        }
+        ds *= v.slope;
+        if (ds < v.resolution) ds = v.resolution;
+        return ds;
+}
+
+/* ======================================================================== */
+/*                                 kernels                                  */
+/* ======================================================================== */
+
+__global__ void k_ecef_from_geodetic(long n, const double * __restrict__ lat,
+    const double * __restrict__ lon, const double * __restrict__ elev,
+    double * __restrict__ ecef)
+{
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
+             r += (long)gridDim.x * blockDim.x) {
+                double x, y, z;
+                d_from_geodetic(lat[r], lon[r], elev[r], x, y, z);
+                ecef[3 * r] = x, ecef[3 * r + 1] = y, ecef[3 * r + 2] = z;
+        }
+}
+
+__global__ void k_ecef_to_geodetic(long n, const double * __restrict__ ecef,
+    double * __restrict__ lat, double * __restrict__ lon, double * __restrict__ alt)
+{
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
+             r += (long)gridDim.x * blockDim.x) {
+                double la, lo, al;
+                d_to_geodetic(ecef[3 * r], ecef[3 * r + 1], ecef[3 * r + 2], la, lo, al);
+                if (lat) lat[r] = la;
+                if (lon) lon[r] = lo;
+                if (alt) alt[r] = al;
+        }
+}
+
+/* [ref ecef.c:160-176] */
+__global__ void k_ecef_from_horizontal(long n, const double * __restrict__ lat,
+    const double * __restrict__ lon, const double * __restrict__ az_,
+    const double * __restrict__ el_, double * __restrict__ dir)
+{
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
+             r += (long)gridDim.x * blockDim.x) {
+                double e[3], nn[3], u[3];
+                d_enu(lat[r], lon[r], e, nn, u);
+                const double az = az_[r] * kPi / 180.;
+                const double el = el_[r] * kPi / 180.;
+                const double ce = cos(el);
+                const double q0 = ce * sin(az), q1 = ce * cos(az), q2 = sin(el);
+                for (int i = 0; i < 3; i++)
+                        dir[3 * r + i] = q0 * e[i] + q1 * nn[i] + q2 * u[i];
+        }
+}
+
+/* [ref ecef.c:178-207] */
+__global__ void k_ecef_to_horizontal(long n, const double * __restrict__ lat,
+    const double * __restrict__ lon, const double * __restrict__ dir,
+    double * __restrict__ az, double * __restrict__ el)
+{
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
+             r += (long)gridDim.x * blockDim.x) {
+                double e[3], nn[3], u[3];
+                d_enu(lat[r], lon[r], e, nn, u);
+                const double d0 = dir[3 * r], d1 = dir[3 * r + 1], d2 = dir[3 * r + 2];
+                const double x = e[0] * d0 + e[1] * d1 + e[2] * d2;
+                const double y = nn[0] * d0 + nn[1] * d1 + nn[2] * d2;
+                const double z = u[0] * d0 + u[1] * d1 + u[2] * d2;
+                double rr = d0 * d0 + d1 * d1 + d2 * d2;
+                if (rr <= FLT_EPSILON) continue; /* outputs untouched [ref ecef.c:194] */
+                rr = sqrt(rr);
+                if (az) az[r] = atan2(x, y) * 180. / kPi;
+                if (el) {
+                        const double arg = z / rr;
+                        el[r] = (arg > 1.) ? 90. :
+                                             ((arg < -1.) ? -90. : asin(arg) * 180. / kPi);
+                }
+        }
+}
+
+/* Elevation of n points on the view's first meta.  For a MAP the arguments
+ * are (x, y) [ref map.c:380-385]; for a STACK (latitude, longitude)
+ * [ref stack.c:338-361]. */
+__global__ void k_elevation(tamd_view v, long n, const double * __restrict__ a,
+    const double * __restrict__ b, double * __restrict__ z, int * __restrict__ inside)
+{
+        const tamd_meta mt = v.metas[0];
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
+             r += (long)gridDim.x * blockDim.x) {
+                double zz = 0.;
+                bool in;
+                if (mt.kind == TAMD_MAP)
+                        in = d_grid_elevation(v.grids[mt.src], a[r], b[r], zz);
+                else
+                        in = d_stack_elevation(v, v.stacks[mt.src], a[r], b[r], zz);
+                /* an outside point leaves a MAP's z untouched in the reference
+                 * and zeroes a STACK's; report 0 for both */
+                z[r] = in ? zz : 0.;
+                inside[r] = in ? 1 : 0;
+        }
+}
+
+/* [ref stepper.c:877-931] */
+__global__ void k_position(tamd_view v, long n, const double * __restrict__ lat,
+    const double * __restrict__ lon, const double * __restrict__ height, int layer,
+    double * __restrict__ pos, int * __restrict__ data_index)
+{
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
+             r += (long)gridDim.x * blockDim.x) {
+                const double la = lat[r], lo = lon[r];
+                int found = -1, di = 0;
+                double elevation = 0.;
+                const int end = v.layer_first[layer + 1];
+                for (int j = v.layer_first[layer]; j < end; j++, di++) {
+                        const tamd_meta mt = v.metas[j];
+                        if (!d_source_elevation(v, mt, la, lo, elevation)) continue;
+                        elevation += mt.offset;
+                        if (v.geoid >= 0) { /* [ref stepper.c:905-914] */
+                                double undulation;
+                                const double l360 = (lo >= 0) ? lo : lo + 360.;
+                                if (d_grid_elevation(
+                                        v.grids[v.geoid], l360, la, undulation))
+                                        elevation += undulation;
+                        }
+                        found = di;
+                        break;
+                }
+                data_index[r] = found;
+                if (found >= 0) {
+                        double x, y, z;
+                        d_from_geodetic(la, lo, elevation + height[r], x, y, z);
+                        pos[3 * r] = x, pos[3 * r + 1] = y, pos[3 * r + 2] = z;
+                }
+        }
+}
+
+/* One turtle_stepper_step per thread [ref stepper.c:780-875].  The bisection
+ * loop diverges (only lanes that crossed a boundary run it); that is accepted
+ * here because this kernel serves single-step callers.  The trace kernel
+ * below is the one that keeps every lane busy. */
+template <int MODE>
+__global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
+    double * __restrict__ pos, const double * __restrict__ dir,
+    double * __restrict__ lat, double * __restrict__ lon, double * __restrict__ alt,
+    double * __restrict__ elev, double * __restrict__ step, int * __restrict__ index,
+    int flags)
+{
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
+             r += (long)gridDim.x * blockDim.x) {
+                double px = pos[3 * r], py = pos[3 * r + 1], pz = pos[3 * r + 2];
+                Sample s;
+                if ((flags & TURTLE_AMD_STEP_RESUME) && (dir != nullptr)) {
+                        /* the caller hands back the sample of this position */
+                        s.lat = lat ? lat[r] : 0., s.lon = lon ? lon[r] : 0.;
+                        s.alt = alt[r];
+                        s.e0 = elev[2 * r], s.e1 = elev[2 * r + 1];
+                        s.m = index[2 * r], s.k = index[2 * r + 1];
+                        if (s.m < 0) s.e0 = s.e1 = 0.;
+                } else
+                        d_sample<MODE>(v, px, py, pz, s);
+
+                double ds = 0.;
+                if (s.m >= 0) {
+                        ds = d_step_length(v, s.alt, s.e0, s.e1, s.m);
+                        if (dir != nullptr) {
+                                const double dx = dir[3 * r], dy = dir[3 * r + 1],
+                                             dz = dir[3 * r + 2];
+                                px += dx * ds, py += dy * ds, pz += dz * ds;
+                                const int medium0 = s.m;
+                                d_sample<MODE>(v, px, py, pz, s);
+                                if (s.m != medium0) { /* [ref stepper.c:832-864] */
+                                        double ds0 = -ds, ds1 = 0.;
+                                        while (ds1 - ds0 > 1E-08) {
+                                                const double ds2 = 0.5 * (ds0 + ds1);
+                                                Sample s2;
+                                                d_sample<MODE>(v, px + dx * ds2,
+                                                    py + dy * ds2, pz + dz * ds2, s2);
+                                                if (s2.m == medium0)
+                                                        ds0 = ds2;
+                                                else {
+                                                        ds1 = ds2;
+                                                        s = s2;
+                                                }
+                                        }
+                                        ds += ds1;
+                                        px += dx * ds1, py += dy * ds1, pz += dz * ds1;
+                                }
+                                pos[3 * r] = px, pos[3 * r + 1] = py, pos[3 * r + 2] = pz;
+                        }
+                }
+                /* sample_publish [ref stepper.c:758-778] */
+                if (lat) lat[r] = s.lat;
+                if (lon) lon[r] = s.lon;
+                if (alt) alt[r] = s.alt;
+                if (elev) {
+                        elev[2 * r] = (s.m >= 0) ? s.e0 : 0.;
+                        elev[2 * r + 1] = (s.m >= 0) ? s.e1 : 0.;
+                }
+                if (step) step[r] = ds;
+                index[2 * r] = s.m, index[2 * r + 1] = s.k;
+        }
+}
+
+/* ---- the hot kernel ---------------------------------------------------- */
+
+constexpr int kChunk = 64; /* rays a wave draws from the global queue at once */
+
+enum { ST_INIT = 0, ST_STEP = 1, ST_BISECT = 2 };
+
+__device__ __forceinline__ ull wave_sum(ull v)
+{
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        return v;
+}
+
+/* Persistent waves; one ray per lane; ONE sample per lane per iteration.
+ *
+ * A ray alternates between optimistic steps (one sample each) and, once, a
+ * ~20-30 sample bisection that locates the boundary it crossed.  Run as the
+ * reference writes it (a while loop inside the step) the bisection would
+ * idle the other 63 lanes of the wave.  Instead each lane carries a small
+ * state machine (INIT -> STEP -> BISECT -> done) and every trip round the loop
+ * evaluates exactly one sample for every live lane, whatever its state: the
+ * expensive part (ECEF->geodetic + layer lookup) is always executed with a
+ * full exec mask, and only the cheap bookkeeping diverges.
+ *
+ * Finished lanes are refilled from a global ray queue: lanes that need a ray
+ * are ranked with ballot/mbcnt, and the wave draws kChunk ray ids at a time
+ * with one atomic (wave-aggregated), so the queue sees n / 64 atomics.
+ *
+ * Results do not depend on which lane runs a ray (rays are independent), so
+ * the output is deterministic.  Arithmetic per ray is that of calling the
+ * reference's turtle_stepper_step in a loop [ref stepper.c:780-875]. */
+template <int MODE>
+__global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
+    double * __restrict__ pos, const double * __restrict__ dir, int max_steps,
+    int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
+    ull * __restrict__ stats, ull * __restrict__ queue)
+{
+        long pool_next = 0, pool_end = 0; /* wave-uniform */
+        bool exhausted = false;            /* wave-uniform */
+
+        long ray = -1;
+        bool dead = false;
+        int state = ST_INIT, count = 0;
+        double px = 0, py = 0, pz = 0, dx = 0, dy = 0, dz = 0, len = 0;
+        double alt = 0, e0 = 0, e1 = 0; /* last accepted sample */
+        int m = -1, k = -1;
+        double bx = 0, by = 0, bz = 0, ds_t = 0, ds0 = 0, ds1 = 0; /* bisection */
+        int bm = -1, bk = -1;
+        ull my_rays = 0, my_steps = 0, my_samples = 0, my_capped = 0;
+
+        for (;;) {
+                /* ---- refill idle lanes from the queue ---- */
+                for (;;) {
+                        const bool need = (ray < 0) && !dead;
+                        const ull mask = __ballot(need);
+                        if (mask == 0) break;
+                        if (pool_next >= pool_end) {
+                                if (exhausted) {
+                                        if (need) dead = true;
+                                        break;
+                                }
+                                ull base = 0;
+                                if ((threadIdx.x & 63) == 0)
+                                        base = atomicAdd(queue, (ull)kChunk);
+                                base = __shfl(base, 0, 64);
+                                pool_next = (long)base;
+                                pool_end = min((long)base + kChunk, n);
+                                if ((long)base >= n) {
+                                        exhausted = true;
+                                        pool_next = pool_end = 0;
+                                }
+                                continue;
+                        }
+                        const long avail = pool_end - pool_next;
+                        const int rank = __builtin_amdgcn_mbcnt_hi(
+                            (unsigned)(mask >> 32),
+                            __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        if (need && (rank < avail)) {
+                                ray = pool_next + rank;
+                                px = pos[3 * ray], py = pos[3 * ray + 1], pz = pos[3 * ray + 2];
+                                dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
+                                len = 0., count = 0, state = ST_INIT;
+                        }
+                        pool_next += min((long)__popcll(mask), avail);
+                }
+                if (__ballot(ray >= 0) == 0) break;
+
+                if (ray >= 0) {
+                        /* ---- where does this lane sample next? ---- */
+                        double ds = 0., ds2 = 0.;
+                        double qx = px, qy = py, qz = pz;
+                        if (state == ST_STEP) {
+                                ds = d_step_length(v, alt, e0, e1, m);
+                                qx = px + dx * ds, qy = py + dy * ds, qz = pz + dz * ds;
+                        } else if (state == ST_BISECT) {
+                                ds2 = 0.5 * (ds0 + ds1);
+                                qx = bx + dx * ds2, qy = by + dy * ds2, qz = bz + dz * ds2;
+                        }
+
+                        Sample s;
+                        d_sample<MODE>(v, qx, qy, qz, s);
+                        my_samples++;
+
+                        /* ---- bookkeeping (cheap, may diverge) ---- */
+                        bool done = false, located = false;
+                        if (state == ST_INIT) {
+                                alt = s.alt, e0 = s.e0, e1 = s.e1, m = s.m, k = s.k;
+                                if ((m < 0) || (max_steps <= 0))
+                                        done = true;
+                                else
+                                        state = ST_STEP;
+                        } else if (state == ST_STEP) {
+                                if (s.m == m) { /* no boundary: accept the step */
+                                        px = qx, py = qy, pz = qz;
+                                        alt = s.alt, e0 = s.e0, e1 = s.e1, k = s.k;
+                                        len += ds;
+                                        if (++count >= max_steps) {
+                                                done = true;
+                                                my_capped++;
+                                        }
+                                } else { /* [ref stepper.c:832-838] */
+                                        bx = qx, by = qy, bz = qz;
+                                        ds_t = ds, ds0 = -ds, ds1 = 0.;
+                                        bm = s.m, bk = s.k;
+                                        state = ST_BISECT;
+                                        located = !(ds1 - ds0 > 1E-08);
+                                }
+                        } else { /* [ref stepper.c:839-860] */
+                                if (s.m == m)
+                                        ds0 = ds2;
+                                else {
+                                        ds1 = ds2;
+                                        bm = s.m, bk = s.k;
+                                }
+                                located = !(ds1 - ds0 > 1E-08);
+                        }
+                        if (located) { /* [ref stepper.c:861-863] */
+                                px = bx + dx * ds1, py = by + dy * ds1, pz = bz + dz * ds1;
+                                len += ds_t + ds1;
+                                count++;
+                                m = bm, k = bk;
+                                done = true;
+                        }
+                        if (done) {
+                                pos[3 * ray] = px, pos[3 * ray + 1] = py, pos[3 * ray + 2] = pz;
+                                index[2 * ray] = m, index[2 * ray + 1] = k;
+                                if (length) length[ray] = len;
+                                if (n_steps) n_steps[ray] = count;
+                                my_rays++;
+                                my_steps += (ull)count;
+                                ray = -1;
+                        }
+                }
+        }
+
+        my_rays = wave_sum(my_rays);
+        my_steps = wave_sum(my_steps);
+        my_samples = wave_sum(my_samples);
+        my_capped = wave_sum(my_capped);
+        if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&stats[0], my_rays);
+                atomicAdd(&stats[1], my_steps);
+                atomicAdd(&stats[2], my_samples);
+                atomicAdd(&stats[3], my_capped);
+        }
+}
+
+/* hits[m + 1] and a linear path-length histogram, exact integer counts.
+ * Per-block LDS counters (32-bit) flushed with one 64-bit atomic per bin. */
+__global__ void __launch_bounds__(256) k_tally(long n, const int * __restrict__ index,
+    const double * __restrict__ length, int n_media, ull * __restrict__ hits,
+    int n_bins, double scale, ull * __restrict__ histogram)
+{
+        extern __shared__ unsigned int lds[];
+        unsigned int * h_hits = lds;                 /* n_media + 1 */
+        unsigned int * h_bins = lds + (n_media + 1); /* n_bins + 1 */
+        const int total = n_media + 1 + n_bins + 1;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) lds[i] = 0;
+        __syncthreads();
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
+             r += (long)gridDim.x * blockDim.x) {
+                const int m = index[2 * r];
+                if ((m >= -1) && (m < n_media)) atomicAdd(&h_hits[m + 1], 1u);
+                const double t = length[r] * scale;
+                int b = n_bins; /* overflow, also NaN and negatives */
+                if ((t >= 0.) && (t < (double)n_bins)) b = (int)t;
+                atomicAdd(&h_bins[b], 1u);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+                const unsigned int c = lds[i];
+                if (c == 0) continue;
+                if (i <= n_media)
+                        atomicAdd(&hits[i], (ull)c);
+                else
+                        atomicAdd(&histogram[i - (n_media + 1)], (ull)c);
+        }
+}
+
+} /* namespace */
+
+/* ======================================================================== */
+/*                         host side of the device layer                    */
+/* ======================================================================== */
+
+static thread_local char g_error[512] = "";
+static int g_device = -1;
+static int g_cus = 0;
+static hipStream_t g_own_stream = nullptr;
+static hipStream_t g_stream = nullptr;
+static void * g_scratch = nullptr;
+static size_t g_scratch_size = 0, g_scratch_used = 0;
+
+static int fail(const char * what, hipError_t e)
+{
+        snprintf(g_error, sizeof(g_error), "%s: %s (HIP error %d)", what,
+            hipGetErrorString(e), (int)e);
+        return 1;
+}
+
+#define HIP_TRY(call)                                                          \
+        do {                                                                   \
+                const hipError_t e_ = (call);                                  \
+                if (e_ != hipSuccess) return fail(#call, e_);                  \
+        } while (0)
+
+extern "C" const char * tamd_dev_error(void) { return g_error; }
+
+extern "C" int tamd_dev_count(void)
+{
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+        return count;
+}
+
+extern "C" int tamd_dev_select(int device)
+{
+        const int count = tamd_dev_count();
+        if (count <= 0) {
+                snprintf(g_error, sizeof(g_error),
+                    "no HIP device is visible: libturtle_amd has no CPU path");
+                return 1;
+        }
+        if ((device < 0) || (device >= count)) {
+                snprintf(g_error, sizeof(g_error),
+                    "invalid device index %d (have %d)", device, count);
+                return 1;
+        }
+        HIP_TRY(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+                snprintf(g_error, sizeof(g_error),
+                    "device %d is %s: libturtle_amd carries gfx950 code only",
+                    device, prop.gcnArchName);
+                return 1;
+        }
+        if (g_device != device) {
+                /* per-device resources are rebuilt lazily */
+                if (g_own_stream) (void)hipStreamDestroy(g_own_stream);
+                g_own_stream = nullptr;
+                if (g_scratch) (void)hipFree(g_scratch);
+                g_scratch = nullptr, g_scratch_size = 0;
+        }
+        g_device = device;
+        g_cus = prop.multiProcessorCount;
+        if (g_own_stream == nullptr)
+                HIP_TRY(hipStreamCreateWithFlags(&g_own_stream, hipStreamNonBlocking));
+        if (g_stream == nullptr) g_stream = g_own_stream;
+        return 0;
+}
+
+extern "C" int tamd_dev_init(void)
+{
+        if (g_device >= 0) {
+                HIP_TRY(hipSetDevice(g_device));
+                return 0;
+        }
+        int device = 0;
+        const char * env = getenv("LOCAL_RANK");
+        if ((env != nullptr) && (*env != 0)) {
+                const int count = tamd_dev_count();
+                if (count > 0) device = atoi(env) % count;
+        }
+        return tamd_dev_select(device);
+}
+
+extern "C" int tamd_dev_current(void) { return g_device; }
+extern "C" int tamd_dev_cus(void) { return (tamd_dev_init() == 0) ? g_cus : 0; }
+
+extern "C" int tamd_dev_stream_set(void * stream)
+{
+        if (tamd_dev_init()) return 1;
+        g_stream = (stream != nullptr) ? (hipStream_t)stream : g_own_stream;
+        return 0;
+}
+
+extern "C" int tamd_dev_sync(void)
+{
+        if (tamd_dev_init()) return 1;
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        return 0;
+}
+
+extern "C" int tamd_dev_malloc(void ** ptr, size_t bytes)
+{
+        *ptr = nullptr;
+        if (tamd_dev_init()) return 1;
+        HIP_TRY(hipMalloc(ptr, bytes ? bytes : 1));
+        return 0;
+}
+
+extern "C" void tamd_dev_free(void * ptr)
+{
+        if (ptr != nullptr) (void)hipFree(ptr);
+}
+
+extern "C" int tamd_dev_h2d(void * dst, const void * src, size_t bytes)
+{
+        if (tamd_dev_init()) return 1;
+        if (bytes == 0) return 0;
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        return 0;
+}
+
+extern "C" int tamd_dev_d2h(void * dst, const void * src, size_t bytes)
+{
+        if (tamd_dev_init()) return 1;
+        if (bytes == 0) return 0;
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        return 0;
+}
+
+extern "C" int tamd_dev_zero(void * dst, size_t bytes)
+{
+        if (tamd_dev_init()) return 1;
+        HIP_TRY(hipMemsetAsync(dst, 0, bytes, g_stream));
+        return 0;
+}
+
+extern "C" void tamd_scratch_reset(void) { g_scratch_used = 0; }
+
+extern "C" int tamd_scratch_get(void ** ptr, size_t bytes)
+{
+        *ptr = nullptr;
+        if (tamd_dev_init()) return 1;
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (g_scratch_used + need > g_scratch_size) {
+                if (g_scratch_used != 0) {
+                        /* pieces already handed out would dangle: the host layer
+                         * sizes the arena up front with one oversize request */
+                        snprintf(g_error, sizeof(g_error), "scratch arena exhausted");
+                        return 1;
+                }
+                HIP_TRY(hipStreamSynchronize(g_stream));
+                if (g_scratch) (void)hipFree(g_scratch);
+                g_scratch = nullptr, g_scratch_size = 0;
+                const size_t size = need + (need >> 2) + (1u << 20);
+                HIP_TRY(hipMalloc(&g_scratch, size));
+                g_scratch_size = size;
+        }
+        *ptr = (char *)g_scratch + g_scratch_used;
+        g_scratch_used += need;
+        return 0;
+}
+
+static int grid_for(long n, int block)
+{
+        long blocks = (n + block - 1) / block;
+        const long cap = (long)(g_cus > 0 ? g_cus : 256) * 8;
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        return (int)blocks;
+}
+
+#define LAUNCH_CHECK(name)                                                     \
+        do {                                                                   \
+                const hipError_t e_ = hipGetLastError();                       \
+                if (e_ != hipSuccess) return fail("launch " name, e_);         \
+        } while (0)
+
+extern "C" int tamd_k_ecef_from_geodetic(long n, const double * lat,
+    const double * lon, const double * elev, double * ecef)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        hipLaunchKernelGGL(k_ecef_from_geodetic, dim3(grid_for(n, 256)), dim3(256), 0,
+            g_stream, n, lat, lon, elev, ecef);
+        LAUNCH_CHECK("k_ecef_from_geodetic");
+        return 0;
+}
+
+extern "C" int tamd_k_ecef_to_geodetic(
+    long n, const double * ecef, double * lat, double * lon, double * alt)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        hipLaunchKernelGGL(k_ecef_to_geodetic, dim3(grid_for(n, 256)), dim3(256), 0,
+            g_stream, n, ecef, lat, lon, alt);
+        LAUNCH_CHECK("k_ecef_to_geodetic");
+        return 0;
+}
+
+extern "C" int tamd_k_ecef_from_horizontal(long n, const double * lat,
+    const double * lon, const double * az, const double * el, double * dir)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        hipLaunchKernelGGL(k_ecef_from_horizontal, dim3(grid_for(n, 256)), dim3(256), 0,
+            g_stream, n, lat, lon, az, el, dir);
+        LAUNCH_CHECK("k_ecef_from_horizontal");
+        return 0;
+}
+
+extern "C" int tamd_k_ecef_to_horizontal(long n, const double * lat,
+    const double * lon, const double * dir, double * az, double * el)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        hipLaunchKernelGGL(k_ecef_to_horizontal, dim3(grid_for(n, 256)), dim3(256), 0,
+            g_stream, n, lat, lon, dir, az, el);
+        LAUNCH_CHECK("k_ecef_to_horizontal");
+        return 0;
+}
+
+extern "C" int tamd_k_elevation(struct tamd_view view, long n, const double * a,
+    const double * b, double * z, int * inside)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        hipLaunchKernelGGL(k_elevation, dim3(grid_for(n, 256)), dim3(256), 0, g_stream,
+            view, n, a, b, z, inside);
+        LAUNCH_CHECK("k_elevation");
+        return 0;
+}
+
+extern "C" int tamd_k_position(struct tamd_view view, long n, const double * lat,
+    const double * lon, const double * height, int layer, double * pos,
+    int * data_index)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        hipLaunchKernelGGL(k_position, dim3(grid_for(n, 256)), dim3(256), 0, g_stream,
+            view, n, lat, lon, height, layer, pos, data_index);
+        LAUNCH_CHECK("k_position");
+        return 0;
+}
+
+extern "C" int tamd_k_step(struct tamd_view view, long n, double * pos,
+    const double * dir, double * lat, double * lon, double * alt, double * elev,
+    double * step, int * index, int flags)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        const dim3 grid(grid_for(n, 256)), block(256);
+#define STEP_CASE(MODE)                                                        \
+        hipLaunchKernelGGL(k_step<MODE>, grid, block, 0, g_stream, view, n, pos, dir,  \
+            lat, lon, alt, elev, step, index, flags)
+        if (view.mode == TAMD_MODE_ONE_MAP)
+                STEP_CASE(TAMD_MODE_ONE_MAP);
+        else if (view.mode == TAMD_MODE_ONE_STACK)
+                STEP_CASE(TAMD_MODE_ONE_STACK);
+        else
+                STEP_CASE(TAMD_MODE_GENERIC);
+#undef STEP_CASE
+        LAUNCH_CHECK("k_step");
+        return 0;
+}
+
+/* Waves per SIMD the trace kernel is launched with.  It is fp64-VALU bound
+ * with a dependent 4-node gather per sample, so a few waves per SIMD are
+ * enough to cover the gather latency; TURTLE_AMD_TRACE_WAVES overrides the
+ * default for experiments. */
+static int trace_blocks_per_cu(const void * kernel)
+{
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 256, 0) !=
+                hipSuccess ||
+            blocks < 1)
+                blocks = 1;
+        const char * env = getenv("TURTLE_AMD_TRACE_WAVES");
+        if ((env != nullptr) && (*env != 0)) {
+                const int waves = atoi(env); /* per SIMD == blocks of 256 per CU */
+                if ((waves >= 1) && (waves < blocks)) blocks = waves;
+        }
+        return blocks;
+}
+
+extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
+    const double * dir, int max_steps, int * index, double * length, int * n_steps,
+    unsigned long long * stats, unsigned long long * queue)
+{
+        if (tamd_dev_init()) return 1;
+        HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
+        HIP_TRY(hipMemsetAsync(queue, 0, sizeof(ull), g_stream));
+        if (n <= 0) return 0;
+        const void * kernel = (view.mode == TAMD_MODE_ONE_MAP) ?
+            (const void *)k_trace<TAMD_MODE_ONE_MAP> :
+            ((view.mode == TAMD_MODE_ONE_STACK) ?
+                    (const void *)k_trace<TAMD_MODE_ONE_STACK> :
+                    (const void *)k_trace<TAMD_MODE_GENERIC>);
+        long blocks = (long)g_cus * trace_blocks_per_cu(kernel);
+        const long useful = (n + 255) / 256;
+        if (blocks > useful) blocks = useful;
+        const dim3 grid((unsigned)blocks), block(256);
+#define TRACE_CASE(MODE)                                                       \
+        hipLaunchKernelGGL(k_trace<MODE>, grid, block, 0, g_stream, view, n, pos, dir, \
+            max_steps, index, length, n_steps, stats, queue)
+        if (view.mode == TAMD_MODE_ONE_MAP)
+                TRACE_CASE(TAMD_MODE_ONE_MAP);
+        else if (view.mode == TAMD_MODE_ONE_STACK)
+                TRACE_CASE(TAMD_MODE_ONE_STACK);
+        else
+                TRACE_CASE(TAMD_MODE_GENERIC);
+#undef TRACE_CASE
+        LAUNCH_CHECK("k_trace");
+        return 0;
+}
+
+extern "C" int tamd_k_tally(long n, const int * index, const double * length,
+    int n_media, unsigned long long * hits, int n_bins, double length_max,
+    unsigned long long * histogram)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        const size_t lds = (size_t)(n_media + 1 + n_bins + 1) * sizeof(unsigned int);
+        if (lds > 64 * 1024) {
+                snprintf(g_error, sizeof(g_error), "too many tally bins (%d)", n_bins);
+                return 1;
+        }
+        const double scale = (double)n_bins / length_max;
+        hipLaunchKernelGGL(k_tally, dim3(grid_for(n, 256)), dim3(256), lds, g_stream, n,
+            index, length, n_media, hits, n_bins, scale, histogram);
+        LAUNCH_CHECK("k_tally");
+        return 0;
+}

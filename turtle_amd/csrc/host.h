@@ -1,0 +1,125 @@
+/*
+ * host.h -- host-side objects behind the opaque handles of turtle_amd.h.
+ * Plain C99; the structures here never reach the device (internal.h has the
+ * POD tables that do).
+ */
+#ifndef TURTLE_AMD_HOST_H
+#define TURTLE_AMD_HOST_H
+
+#include "internal.h"
+
+/* ---- error context [ref src/turtle/error.h:31-47] --------------------- */
+struct tamd_error {
+        enum turtle_return code;
+        turtle_function_t * function;
+};
+
+#define TAMD_ERROR_INIT(fn)                                                    \
+        struct tamd_error error_ = { TURTLE_RETURN_SUCCESS,                    \
+                (turtle_function_t *)(fn) }
+
+/* Record + raise in one go: formats "{ fn [#code], file:line } text" and calls
+ * the installed handler once [ref src/turtle/error.c:108-138]. */
+enum turtle_return tamd_raise_(struct tamd_error * error, enum turtle_return rc,
+    const char * file, int line, const char * format, ...);
+#define TAMD_RAISE(rc, ...) tamd_raise_(&error_, (rc), __FILE__, __LINE__, __VA_ARGS__)
+/* device-layer failure => LIBRARY_ERROR carrying the HIP message */
+#define TAMD_RAISE_DEVICE()                                                    \
+        TAMD_RAISE(TURTLE_RETURN_LIBRARY_ERROR, "device error: %s", tamd_dev_error())
+
+/* ---- maps ---------------------------------------------------------------- */
+struct turtle_map {
+        /* meta data [ref src/turtle/map.h:41-56] */
+        int nx, ny;
+        double x0, y0, z0;
+        double dx, dy, dz;
+        char encoding[8];
+        int is_signed;        /* int16 codecs (hgt): z = (int16)v */
+        struct turtle_stack * stack; /* owner, or NULL */
+
+        uint16_t * nodes;     /* host copy: native endian, rows south->north */
+        void * d_nodes;       /* HBM copy, same layout */
+        int d_stale;          /* host copy changed since the last upload */
+};
+
+/* fills the decode parameters of `grid` and makes the HBM copy current */
+int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid);
+enum turtle_return tamd_map_load_(struct turtle_map ** map, const char * path,
+    struct tamd_error * error, const char * file, int line);
+/* hgt.c: header-only probe and full read */
+int tamd_hgt_probe(const char * path, struct turtle_map * meta);
+int tamd_hgt_read(const char * path, struct turtle_map * map);
+
+/* ---- stacks -------------------------------------------------------------- */
+struct turtle_stack {
+        int max_size;
+        turtle_stack_locker_t * lock, * unlock;
+        double latitude_0, latitude_delta;
+        double longitude_0, longitude_delta;
+        int latitude_n, longitude_n;
+        char * root;
+        char ** path;             /* [lat_n * long_n] file of each slot or NULL */
+        struct turtle_map ** tile; /* [lat_n * long_n] loaded tile or NULL */
+        int n_loaded;
+};
+
+/* load every tile that has a file (HBM holds them all); 0 on success, else an
+ * enum turtle_return with a message in `message` */
+int tamd_stack_load_all(struct turtle_stack * stack, char * message, size_t size);
+
+struct turtle_client {
+        struct turtle_stack * stack;
+};
+
+/* ---- stepper ------------------------------------------------------------- */
+struct tamd_data {
+        int kind;                    /* enum tamd_kind */
+        struct turtle_map * map;
+        struct turtle_stack * stack;
+        struct turtle_client * client; /* owned, when the stack has a lock */
+};
+
+struct tamd_layer_meta {
+        int data; /* index into stepper->data */
+        double offset;
+};
+
+struct tamd_layer {
+        struct tamd_layer_meta * meta; /* in the order they were added */
+        int size, capacity;
+};
+
+struct turtle_stepper {
+        struct tamd_data * data;
+        int n_data, cap_data;
+        struct tamd_layer * layers;
+        int n_layers, cap_layers;
+        struct turtle_map * geoid;
+        double local_range, slope_factor, resolution_factor;
+
+        /* device tables (rebuilt when the global geometry epoch moves) */
+        unsigned long epoch;
+        void * d_tables;
+        size_t d_tables_size;
+        struct tamd_view view;
+        unsigned long long * d_stats; /* 4 stats + 1 queue counter */
+};
+
+/* Any change to what kernels may read (map nodes, tiles, layers) bumps this. */
+extern unsigned long tamd_geometry_epoch;
+
+/* Builds/refreshes stepper->view; returns an enum turtle_return and a message */
+int tamd_stepper_flatten(struct turtle_stepper * stepper, char * message, size_t size);
+
+/* ---- HOST/DEVICE array staging for the batch calls ----------------------- */
+struct tamd_stage {
+        int space;
+};
+int tamd_stage_begin(struct tamd_stage * st, int space, size_t total_bytes);
+/* returns the device address to use for a user array (NULL stays NULL) */
+int tamd_stage_in(struct tamd_stage * st, const void * user, size_t bytes, void ** dev);
+int tamd_stage_out(struct tamd_stage * st, void * user, size_t bytes, void ** dev);
+int tamd_stage_fetch(struct tamd_stage * st, void * user, size_t bytes, const void * dev);
+int tamd_stage_end(struct tamd_stage * st);
+
+#endif

@@ -1,0 +1,140 @@
+/*
+ * internal.h -- declarations shared by the host C objects and the HIP device
+ * layer of libturtle_amd.  Not installed.
+ *
+ * Split of responsibilities:
+ *   host (C99: error.c map.c hgt.c stack.c client.c stepper.c ecef.c batch.c)
+ *        owns the opaque handles of the public API, file ingest, the error
+ *        convention, and flattening a stepper into the POD tables below;
+ *   device (device.hip) owns HBM, the stream, and every kernel.  All
+ *        arithmetic of the path happens there.
+ */
+#ifndef TURTLE_AMD_INTERNAL_H
+#define TURTLE_AMD_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "turtle_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* POD tables read by the kernels (layout shared by host and device code)   */
+/* ------------------------------------------------------------------------ */
+
+/* One DEM grid resident in HBM: 16-bit nodes, native little-endian, rows
+ * south->north, row-major [ny][nx].  Decoding the file format (byte order,
+ * row flip, sign) happens ONCE at upload instead of per node access as the
+ * reference's get_z callbacks do [ref src/turtle/map.h:47-49,
+ * io/hgt.c:127-131, map.c:41-44]; integers are exact, so parity is
+ * unaffected.  z = z0 + v * dz with v read as int16 if is_signed else uint16
+ * (signed codecs use z0 = 0, dz = 1, which reproduces "(int16)v" exactly). */
+struct tamd_grid {
+        const uint16_t * nodes;
+        int nx, ny;
+        double x0, y0, dx, dy;
+        double z0, dz;
+        int is_signed;
+        int pad_;
+};
+
+/* Tile directory of a stack [ref src/turtle/stack.h:32-49]: O(1) lookup
+ * replaces the reference's MRU list scan [ref stack.c:300-335]. */
+struct tamd_stack {
+        double lat0, lon0, dlat, dlon;
+        int nlat, nlon;
+        int tile_first; /* offset into the tiles[] table: grid index or -1 */
+        int pad_;
+};
+
+enum tamd_kind { TAMD_FLAT = 0, TAMD_MAP = 1, TAMD_STACK = 2 };
+
+/* One (data, offset) entry of a layer [ref src/turtle/stepper.h:80-85], stored
+ * in the reference's iteration order: last added first [ref stepper.c:722-724] */
+struct tamd_meta {
+        int kind; /* enum tamd_kind */
+        int src;  /* grid index (MAP) or stack index (STACK) */
+        double offset;
+};
+
+enum tamd_mode {
+        TAMD_MODE_GENERIC = 0,   /* any layers / data / geoid */
+        TAMD_MODE_ONE_MAP = 1,   /* one layer, one geodetic map, no geoid */
+        TAMD_MODE_ONE_STACK = 2  /* one layer, one stack, no geoid */
+};
+
+/* Everything a kernel needs about a stepper, passed BY VALUE as a kernel
+ * argument so that it sits in scalar registers. */
+struct tamd_view {
+        const struct tamd_grid * grids;
+        const struct tamd_stack * stacks;
+        const int * tiles;
+        const struct tamd_meta * metas;
+        const int * layer_first; /* n_layers + 1 offsets into metas */
+        int n_layers;
+        int geoid; /* grid index or -1 */
+        double slope, resolution;
+        int mode; /* enum tamd_mode */
+        int pad_;
+};
+
+/* ------------------------------------------------------------------------ */
+/* Device layer (device.hip).  Every function returns 0 on success or a     */
+/* non-zero value after recording a message readable with tamd_dev_error(). */
+/* ------------------------------------------------------------------------ */
+
+const char * tamd_dev_error(void);
+int tamd_dev_init(void);   /* idempotent; selects the device, makes the stream */
+int tamd_dev_count(void);
+int tamd_dev_select(int device);
+int tamd_dev_current(void);
+int tamd_dev_cus(void);
+int tamd_dev_stream_set(void * stream);
+int tamd_dev_sync(void);
+
+int tamd_dev_malloc(void ** ptr, size_t bytes);
+void tamd_dev_free(void * ptr);
+int tamd_dev_h2d(void * dst, const void * src, size_t bytes); /* stream-ordered, then synced */
+int tamd_dev_d2h(void * dst, const void * src, size_t bytes);
+int tamd_dev_zero(void * dst, size_t bytes);                   /* stream-ordered */
+
+/* Grow-only scratch arena for HOST-space calls: reset at the start of each
+ * API call, handed out in 256-byte aligned pieces. */
+void tamd_scratch_reset(void);
+int tamd_scratch_get(void ** ptr, size_t bytes);
+
+/* Kernel launchers.  All pointers are DEVICE pointers; NULL output pointers
+ * are allowed where the public API allows them. */
+int tamd_k_ecef_from_geodetic(long n, const double * lat, const double * lon,
+    const double * elev, double * ecef);
+int tamd_k_ecef_to_geodetic(long n, const double * ecef, double * lat,
+    double * lon, double * alt);
+int tamd_k_ecef_from_horizontal(long n, const double * lat, const double * lon,
+    const double * az, const double * el, double * dir);
+int tamd_k_ecef_to_horizontal(long n, const double * lat, const double * lon,
+    const double * dir, double * az, double * el);
+/* elevation of n points on metas[0] of the view (a MAP or a STACK entry) */
+int tamd_k_elevation(struct tamd_view view, long n, const double * a,
+    const double * b, double * z, int * inside);
+int tamd_k_position(struct tamd_view view, long n, const double * lat,
+    const double * lon, const double * height, int layer, double * pos,
+    int * data_index);
+int tamd_k_step(struct tamd_view view, long n, double * pos,
+    const double * dir, double * lat, double * lon, double * alt,
+    double * elev, double * step, int * index, int flags);
+/* stats: 4 x uint64 on the device (rays, steps, samples, capped);
+ * queue: 1 x uint64 work counter; both zeroed by the launcher. */
+int tamd_k_trace(struct tamd_view view, long n, double * pos,
+    const double * dir, int max_steps, int * index, double * length,
+    int * n_steps, unsigned long long * stats, unsigned long long * queue);
+int tamd_k_tally(long n, const int * index, const double * length,
+    int n_media, unsigned long long * hits, int n_bins, double length_max,
+    unsigned long long * histogram);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

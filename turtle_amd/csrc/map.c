@@ -1,0 +1,295 @@
+/*
+ * map.c -- a single DEM grid: host handle, HBM residency, scalar and batch
+ * elevation [ref src/turtle/map.c:54-421].  The bilinear arithmetic itself is
+ * in device.hip (d_grid_elevation); nothing here interpolates.
+ */
+#include "host.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+unsigned long tamd_geometry_epoch = 1;
+
+/* [ref map.c:54-99] */
+enum turtle_return turtle_map_create(struct turtle_map ** map,
+    const struct turtle_map_info * info, const char * projection)
+{
+        TAMD_ERROR_INIT(&turtle_map_create);
+        *map = NULL;
+        if ((info->nx <= 0) || (info->ny <= 0) || (info->z[0] == info->z[1]))
+                return TAMD_RAISE(
+                    TURTLE_RETURN_DOMAIN_ERROR, "invalid input parameter(s)");
+        if (projection != NULL)
+                return TAMD_RAISE(TURTLE_RETURN_BAD_PROJECTION,
+                    "projected maps are not supported yet (`%s')", projection);
+
+        struct turtle_map * m = calloc(1, sizeof(*m));
+        if (m != NULL) m->nodes = calloc((size_t)info->nx * info->ny, sizeof(*m->nodes));
+        if ((m == NULL) || (m->nodes == NULL)) {
+                free(m);
+                return TAMD_RAISE(
+                    TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
+        }
+        m->nx = info->nx;
+        m->ny = info->ny;
+        m->x0 = info->x[0];
+        m->y0 = info->y[0];
+        m->z0 = info->z[0];
+        m->dx = (info->nx > 1) ? (info->x[1] - info->x[0]) / (info->nx - 1) : 0.;
+        m->dy = (info->ny > 1) ? (info->y[1] - info->y[0]) / (info->ny - 1) : 0.;
+        m->dz = (info->z[1] - info->z[0]) / 65535;
+        strcpy(m->encoding, "none");
+        m->d_stale = 1;
+        *map = m;
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* [ref map.c:102-113] */
+void turtle_map_destroy(struct turtle_map ** map)
+{
+        if ((map == NULL) || (*map == NULL)) return;
+        struct turtle_map * m = *map;
+        if (m->stack != NULL) { /* a tile leaves its stack */
+                struct turtle_stack * s = m->stack;
+                const int n = s->latitude_n * s->longitude_n;
+                int i;
+                for (i = 0; i < n; i++) {
+                        if (s->tile[i] == m) {
+                                s->tile[i] = NULL;
+                                s->n_loaded--;
+                        }
+                }
+        }
+        if (m->d_nodes != NULL) {
+                tamd_dev_sync(); /* no kernel may still be reading it */
+                tamd_dev_free(m->d_nodes);
+        }
+        tamd_geometry_epoch++;
+        free(m->nodes);
+        free(m);
+        *map = NULL;
+}
+
+/* Extension dispatch [ref src/turtle/io.c:60-104]: hgt only, for now. */
+enum turtle_return tamd_map_load_(struct turtle_map ** map, const char * path,
+    struct tamd_error * error, const char * file, int line)
+{
+        *map = NULL;
+        const char * ext = strrchr(path, '.');
+        if (ext == NULL)
+                return tamd_raise_(error, TURTLE_RETURN_BAD_EXTENSION, file, line,
+                    "missing file extension");
+        if (strcmp(ext + 1, "hgt") != 0)
+                return tamd_raise_(error, TURTLE_RETURN_BAD_EXTENSION, file, line,
+                    "unsuported file format `%s'", ext + 1);
+
+        struct turtle_map * m = calloc(1, sizeof(*m));
+        if (m == NULL)
+                return tamd_raise_(error, TURTLE_RETURN_MEMORY_ERROR, file, line,
+                    "could not allocate memory for map `%s'", path);
+        int rc = tamd_hgt_probe(path, m);
+        if (rc == TURTLE_RETURN_SUCCESS) {
+                m->nodes = malloc((size_t)m->nx * m->ny * sizeof(*m->nodes));
+                rc = (m->nodes == NULL) ? TURTLE_RETURN_MEMORY_ERROR :
+                                          tamd_hgt_read(path, m);
+        }
+        if (rc != TURTLE_RETURN_SUCCESS) {
+                free(m->nodes);
+                free(m);
+                const char * text = (rc == TURTLE_RETURN_PATH_ERROR) ?
+                    "could not open file `%s'" :
+                    ((rc == TURTLE_RETURN_MEMORY_ERROR) ?
+                            "could not allocate memory for map `%s'" :
+                            ((rc == TURTLE_RETURN_BAD_FORMAT + 100) ?
+                                    "missing data when reading file `%s'" :
+                                    "invalid hgt filename for `%s'"));
+                if (rc == TURTLE_RETURN_BAD_FORMAT + 100) rc = TURTLE_RETURN_BAD_FORMAT;
+                return tamd_raise_(error, (enum turtle_return)rc, file, line, text, path);
+        }
+        m->d_stale = 1;
+        *map = m;
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* [ref map.c:157-162] */
+enum turtle_return turtle_map_load(struct turtle_map ** map, const char * path)
+{
+        TAMD_ERROR_INIT(&turtle_map_load);
+        return tamd_map_load_(map, path, &error_, __FILE__, __LINE__);
+}
+
+/* [ref map.c:183-205]; the 16-bit code is written as map.c:47-51 (default
+ * encoding) or as a plain int16 (hgt; the reference's own setter,
+ * io/hgt.c:133-137, byte-swaps after converting the double, which we do not
+ * reproduce: the stored value here is the elevation itself). */
+enum turtle_return turtle_map_fill(
+    struct turtle_map * map, int ix, int iy, double elevation)
+{
+        TAMD_ERROR_INIT(&turtle_map_fill);
+        if (map == NULL)
+                return TAMD_RAISE(
+                    TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
+        if ((ix < 0) || (ix >= map->nx) || (iy < 0) || (iy >= map->ny))
+                return TAMD_RAISE(
+                    TURTLE_RETURN_DOMAIN_ERROR, "point is outside of map");
+        if ((map->dz <= 0.) && (elevation != map->z0))
+                return TAMD_RAISE(
+                    TURTLE_RETURN_DOMAIN_ERROR, "inconsistent elevation value");
+        if ((elevation < map->z0) || (elevation > map->z0 + 65535 * map->dz))
+                return TAMD_RAISE(TURTLE_RETURN_DOMAIN_ERROR,
+                    "elevation is outside of map span");
+        uint16_t code;
+        if (map->is_signed)
+                code = (uint16_t)(int16_t)elevation;
+        else
+                code = (uint16_t)round((elevation - map->z0) / map->dz);
+        map->nodes[(size_t)iy * map->nx + ix] = code;
+        map->d_stale = 1;
+        tamd_geometry_epoch++;
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* [ref map.c:208-226]: node coordinates and its stored value (a decode of one
+ * 16-bit code, not an interpolation) */
+enum turtle_return turtle_map_node(const struct turtle_map * map, int ix, int iy,
+    double * x, double * y, double * elevation)
+{
+        TAMD_ERROR_INIT(&turtle_map_node);
+        if (map == NULL)
+                return TAMD_RAISE(
+                    TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
+        if ((ix < 0) || (ix >= map->nx) || (iy < 0) || (iy >= map->ny))
+                return TAMD_RAISE(
+                    TURTLE_RETURN_DOMAIN_ERROR, "point is outside of map");
+        if (x != NULL) *x = map->x0 + ix * map->dx;
+        if (y != NULL) *y = map->y0 + iy * map->dy;
+        if (elevation != NULL) {
+                const uint16_t code = map->nodes[(size_t)iy * map->nx + ix];
+                *elevation = map->is_signed ? (double)(int16_t)code :
+                                              map->z0 + code * map->dz;
+        }
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* [ref map.c:394-400]: no projected maps yet, so always NULL */
+const struct turtle_projection * turtle_map_projection(const struct turtle_map * map)
+{
+        (void)map;
+        return NULL;
+}
+
+/* [ref map.c:403-421] */
+void turtle_map_meta(const struct turtle_map * map, struct turtle_map_info * info,
+    const char ** projection)
+{
+        if (info != NULL) {
+                info->nx = map->nx;
+                info->ny = map->ny;
+                info->x[0] = map->x0;
+                info->x[1] = map->x0 + (map->nx - 1) * map->dx;
+                info->y[0] = map->y0;
+                info->y[1] = map->y0 + (map->ny - 1) * map->dy;
+                info->z[0] = map->z0;
+                info->z[1] = map->z0 + 65535 * map->dz;
+                info->encoding = map->encoding;
+        }
+        if (projection != NULL) *projection = NULL;
+}
+
+int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
+{
+        const size_t bytes = (size_t)map->nx * map->ny * sizeof(*map->nodes);
+        if (map->d_nodes == NULL) {
+                if (tamd_dev_malloc(&map->d_nodes, bytes)) return 1;
+                map->d_stale = 1;
+        }
+        if (map->d_stale) {
+                if (tamd_dev_h2d(map->d_nodes, map->nodes, bytes)) return 1;
+                map->d_stale = 0;
+        }
+        if (grid != NULL) {
+                grid->nodes = map->d_nodes;
+                grid->nx = map->nx, grid->ny = map->ny;
+                grid->x0 = map->x0, grid->y0 = map->y0;
+                grid->dx = map->dx, grid->dy = map->dy;
+                /* int16 codecs return the code itself [ref io/hgt.c:127-131] */
+                grid->z0 = map->is_signed ? 0. : map->z0;
+                grid->dz = map->is_signed ? 1. : map->dz;
+                grid->is_signed = map->is_signed;
+                grid->pad_ = 0;
+        }
+        return 0;
+}
+
+/* A one-grid view for the elevation kernel: tables live in the scratch arena */
+static int map_view(struct turtle_map * map, struct tamd_view * view)
+{
+        struct {
+                struct tamd_grid grid;
+                struct tamd_meta meta;
+        } tables;
+        memset(&tables, 0, sizeof(tables));
+        if (tamd_map_sync(map, &tables.grid)) return 1;
+        tables.meta.kind = TAMD_MAP;
+        void * dev;
+        if (tamd_scratch_get(&dev, sizeof(tables))) return 1;
+        if (tamd_dev_h2d(dev, &tables, sizeof(tables))) return 1;
+        memset(view, 0, sizeof(*view));
+        view->grids = (const struct tamd_grid *)dev;
+        view->metas = (const struct tamd_meta *)((char *)dev + sizeof(struct tamd_grid));
+        view->n_layers = 1;
+        view->geoid = -1;
+        return 0;
+}
+
+static int map_elevation_n(struct turtle_map * map, long n, const double * x,
+    const double * y, double * elevation, int * inside, int space)
+{
+        struct tamd_stage st;
+        struct tamd_view view;
+        void *dx, *dy, *dz, *di;
+        const size_t nb = (size_t)n * sizeof(double);
+        if (tamd_stage_begin(&st, space, 3 * nb + n * sizeof(int) + 4096)) return 1;
+        if (space == TURTLE_AMD_DEVICE) tamd_scratch_reset();
+        if (map_view(map, &view)) return 1;
+        if (tamd_stage_in(&st, x, nb, &dx) || tamd_stage_in(&st, y, nb, &dy) ||
+            tamd_stage_out(&st, elevation, nb, &dz) ||
+            tamd_stage_out(&st, inside, n * sizeof(int), &di))
+                return 1;
+        if (tamd_k_elevation(view, n, dx, dy, dz, di)) return 1;
+        if (tamd_stage_fetch(&st, elevation, nb, dz) ||
+            tamd_stage_fetch(&st, inside, n * sizeof(int), di))
+                return 1;
+        /* the one-grid tables sit in the scratch arena: finish before reuse */
+        return tamd_dev_sync();
+}
+
+enum turtle_return turtle_map_elevation_n(const struct turtle_map * map, long n,
+    const double * x, const double * y, double * elevation, int * inside, int space)
+{
+        TAMD_ERROR_INIT(&turtle_map_elevation_n);
+        if ((map == NULL) || (inside == NULL) || (elevation == NULL))
+                return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
+        if (map_elevation_n((struct turtle_map *)map, n, x, y, elevation, inside, space))
+                return TAMD_RAISE_DEVICE();
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* [ref map.c:380-385 -> :229-277] */
+enum turtle_return turtle_map_elevation(const struct turtle_map * map, double x,
+    double y, double * elevation, int * inside)
+{
+        TAMD_ERROR_INIT(&turtle_map_elevation);
+        double z = 0.;
+        int in = 0;
+        if (map_elevation_n((struct turtle_map *)map, 1, &x, &y, &z, &in, TURTLE_AMD_HOST))
+                return TAMD_RAISE_DEVICE();
+        if (in) *elevation = z; /* an outside point leaves *elevation untouched */
+        if (inside != NULL)
+                *inside = in;
+        else if (!in)
+                return TAMD_RAISE(
+                    TURTLE_RETURN_DOMAIN_ERROR, "point is outside of map");
+        return TURTLE_RETURN_SUCCESS;
+}

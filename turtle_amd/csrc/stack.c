@@ -1,0 +1,354 @@
+/*
+ * stack.c -- a directory of equally sized tiles covering a lat/lon lattice
+ * [ref src/turtle/stack.c:46-450].
+ *
+ * Host side: scan the directory, build the slot -> file table, load tiles.
+ * Device side: the table becomes a flat tile directory (struct tamd_stack) and
+ * every loaded tile stays resident in HBM, so a lookup is O(1) instead of the
+ * reference's MRU list walk [ref stack.c:300-335] and never touches the disk
+ * while stepping.  `stack_size` (max_size) is kept for API compatibility; with
+ * 288 GB of HBM there is nothing to evict for the configurations in scope.
+ */
+#include "host.h"
+
+#include <dirent.h>
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+static int is_tile_file(const char * name)
+{
+        const char * ext = strrchr(name, '.');
+        return (ext != NULL) && (strcmp(ext + 1, "hgt") == 0);
+}
+
+/* [ref stack.c:46-213] */
+enum turtle_return turtle_stack_create(struct turtle_stack ** stack,
+    const char * path, int size, turtle_stack_locker_t * lock,
+    turtle_stack_locker_t * unlock)
+{
+        TAMD_ERROR_INIT(&turtle_stack_create);
+        *stack = NULL;
+        if (((lock == NULL) && (unlock != NULL)) || ((unlock == NULL) && (lock != NULL)))
+                return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "inconsistent lock & unlock");
+
+        DIR * dir = opendir(path);
+        if (dir == NULL)
+                return TAMD_RAISE(TURTLE_RETURN_PATH_ERROR, "could not access %s", path);
+
+        /* first pass: lattice extents and tile span [ref stack.c:60-124] */
+        double lat_min = DBL_MAX, long_min = DBL_MAX;
+        double lat_max = -DBL_MAX, long_max = -DBL_MAX;
+        double lat_delta = 0., long_delta = 0.;
+        struct dirent * entry;
+        char file[4096];
+        while ((entry = readdir(dir)) != NULL) {
+                snprintf(file, sizeof(file), "%s/%s", path, entry->d_name);
+                struct stat sb;
+                if ((stat(file, &sb) != 0) || S_ISDIR(sb.st_mode)) continue;
+                if (!is_tile_file(entry->d_name)) continue; /* unknown format */
+                struct turtle_map meta;
+                const int rc = tamd_hgt_probe(file, &meta);
+                if (rc != TURTLE_RETURN_SUCCESS) {
+                        closedir(dir);
+                        return TAMD_RAISE((enum turtle_return)rc,
+                            (rc == TURTLE_RETURN_PATH_ERROR) ?
+                                "could not open file `%s'" :
+                                "invalid hgt filename for `%s'",
+                            file);
+                }
+                const double dx = meta.dx * (meta.nx - 1);
+                const double dy = meta.dy * (meta.ny - 1);
+                if (long_delta == 0.)
+                        long_delta = dx;
+                else if (long_delta != dx) {
+                        closedir(dir);
+                        return TAMD_RAISE(
+                            TURTLE_RETURN_BAD_FORMAT, "inconsistent longitude span");
+                }
+                if (lat_delta == 0.)
+                        lat_delta = dy;
+                else if (lat_delta != dy) {
+                        closedir(dir);
+                        return TAMD_RAISE(
+                            TURTLE_RETURN_BAD_FORMAT, "inconsistent latitude span");
+                }
+                if (meta.x0 < long_min) long_min = meta.x0;
+                if (meta.y0 < lat_min) lat_min = meta.y0;
+                if (meta.x0 + dx > long_max) long_max = meta.x0 + dx;
+                if (meta.y0 + dy > lat_max) lat_max = meta.y0 + dy;
+        }
+
+        int lat_n = 0, long_n = 0; /* [ref stack.c:127-140] */
+        if ((lat_delta > 0.) && (long_delta > 0.)) {
+                const double dx = (long_max - long_min) / long_delta;
+                long_n = (int)(dx + FLT_EPSILON);
+                const double dy = (lat_max - lat_min) / lat_delta;
+                lat_n = (int)(dy + FLT_EPSILON);
+                if ((fabs(long_n - dx) > FLT_EPSILON) || (fabs(lat_n - dy) > FLT_EPSILON)) {
+                        closedir(dir);
+                        return TAMD_RAISE(TURTLE_RETURN_BAD_FORMAT,
+                            (fabs(long_n - dx) > FLT_EPSILON) ? "invalid longitude grid" :
+                                                                "invalid latitude grid");
+                }
+        }
+
+        struct turtle_stack * s = calloc(1, sizeof(*s));
+        const size_t slots = (size_t)lat_n * long_n;
+        if (s != NULL) {
+                s->root = strdup(path);
+                s->path = calloc(slots ? slots : 1, sizeof(*s->path));
+                s->tile = calloc(slots ? slots : 1, sizeof(*s->tile));
+        }
+        if ((s == NULL) || (s->root == NULL) || (s->path == NULL) || (s->tile == NULL)) {
+                closedir(dir);
+                if (s != NULL) {
+                        free(s->root), free(s->path), free(s->tile);
+                        free(s);
+                }
+                return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
+        }
+        s->max_size = (size > 0) ? size : INT_MAX;
+        s->lock = lock, s->unlock = unlock;
+        s->latitude_0 = lat_min, s->longitude_0 = long_min;
+        s->latitude_delta = lat_delta, s->longitude_delta = long_delta;
+        s->latitude_n = lat_n, s->longitude_n = long_n;
+
+        /* second pass: slot -> file [ref stack.c:167-198] */
+        rewinddir(dir);
+        while ((slots > 0) && ((entry = readdir(dir)) != NULL)) {
+                snprintf(file, sizeof(file), "%s/%s", path, entry->d_name);
+                struct stat sb;
+                if ((stat(file, &sb) != 0) || S_ISDIR(sb.st_mode)) continue;
+                if (!is_tile_file(entry->d_name)) continue;
+                struct turtle_map meta;
+                if (tamd_hgt_probe(file, &meta) != TURTLE_RETURN_SUCCESS) continue;
+                const int ix = (int)((meta.x0 - long_min) / long_delta);
+                const int iy = (int)((meta.y0 - lat_min) / lat_delta);
+                const size_t i = (size_t)iy * long_n + ix;
+                free(s->path[i]);
+                s->path[i] = strdup(file);
+        }
+        closedir(dir);
+        *stack = s;
+        return TURTLE_RETURN_SUCCESS;
+}
+
+static void stack_release_tiles(struct turtle_stack * s)
+{
+        const int n = s->latitude_n * s->longitude_n;
+        int i;
+        for (i = 0; i < n; i++) {
+                if (s->tile[i] == NULL) continue;
+                struct turtle_map * m = s->tile[i];
+                m->stack = NULL; /* do not walk back into the table */
+                turtle_map_destroy(&m);
+                s->tile[i] = NULL;
+        }
+        s->n_loaded = 0;
+        tamd_geometry_epoch++;
+}
+
+/* [ref stack.c:228-237] */
+void turtle_stack_destroy(struct turtle_stack ** stack)
+{
+        if ((stack == NULL) || (*stack == NULL)) return;
+        struct turtle_stack * s = *stack;
+        stack_release_tiles(s);
+        const int n = s->latitude_n * s->longitude_n;
+        int i;
+        for (i = 0; i < n; i++) free(s->path[i]);
+        free(s->path), free(s->tile), free(s->root);
+        free(s);
+        *stack = NULL;
+}
+
+/* [ref stack.c:240-254] */
+enum turtle_return turtle_stack_clear(struct turtle_stack * stack)
+{
+        TAMD_ERROR_INIT(&turtle_stack_clear);
+        if ((stack->lock != NULL) && (stack->lock() != 0))
+                return TAMD_RAISE(TURTLE_RETURN_LOCK_ERROR, "could not acquire the lock");
+        stack_release_tiles(stack);
+        if ((stack->unlock != NULL) && (stack->unlock() != 0))
+                return TAMD_RAISE(TURTLE_RETURN_UNLOCK_ERROR, "could not release the lock");
+        return TURTLE_RETURN_SUCCESS;
+}
+
+int tamd_stack_load_all(struct turtle_stack * s, char * message, size_t size)
+{
+        const int n = s->latitude_n * s->longitude_n;
+        int i;
+        for (i = 0; i < n; i++) {
+                if ((s->path[i] == NULL) || (s->tile[i] != NULL)) continue;
+                struct turtle_map * m = calloc(1, sizeof(*m));
+                int rc = (m == NULL) ? TURTLE_RETURN_MEMORY_ERROR :
+                                       tamd_hgt_probe(s->path[i], m);
+                if (rc == TURTLE_RETURN_SUCCESS) {
+                        m->nodes = malloc((size_t)m->nx * m->ny * sizeof(*m->nodes));
+                        rc = (m->nodes == NULL) ? TURTLE_RETURN_MEMORY_ERROR :
+                                                  tamd_hgt_read(s->path[i], m);
+                }
+                if (rc != TURTLE_RETURN_SUCCESS) {
+                        if (m != NULL) free(m->nodes);
+                        free(m);
+                        if (rc > N_TURTLE_RETURNS) rc = TURTLE_RETURN_BAD_FORMAT;
+                        snprintf(message, size, "could not load tile `%s'", s->path[i]);
+                        return rc;
+                }
+                m->stack = s;
+                m->d_stale = 1;
+                s->tile[i] = m;
+                s->n_loaded++;
+                tamd_geometry_epoch++;
+        }
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* [ref stack.c:257-297]: bring the tiles into memory (here: every tile, and
+ * they go on to HBM at the next device call) */
+enum turtle_return turtle_stack_load(struct turtle_stack * stack)
+{
+        TAMD_ERROR_INIT(&turtle_stack_load);
+        if ((stack->latitude_n == 0) || (stack->longitude_n == 0))
+                return TURTLE_RETURN_SUCCESS;
+        if ((stack->lock != NULL) && (stack->lock() != 0))
+                return TAMD_RAISE(TURTLE_RETURN_LOCK_ERROR, "could not acquire the lock");
+        char message[4200];
+        const int rc = tamd_stack_load_all(stack, message, sizeof(message));
+        if ((stack->unlock != NULL) && (stack->unlock() != 0))
+                return TAMD_RAISE(TURTLE_RETURN_UNLOCK_ERROR, "could not release the lock");
+        if (rc != TURTLE_RETURN_SUCCESS)
+                return TAMD_RAISE((enum turtle_return)rc, "%s", message);
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* One-stack view for the elevation kernel.  Returns 0, -1 on a device error,
+ * or a positive enum turtle_return with `message` set. */
+static int stack_view(struct turtle_stack * s, struct tamd_view * view, char * message,
+    size_t size)
+{
+        int rc = tamd_stack_load_all(s, message, size);
+        if (rc != TURTLE_RETURN_SUCCESS) return rc;
+        const int slots = s->latitude_n * s->longitude_n;
+        const size_t bytes = sizeof(struct tamd_stack) + sizeof(struct tamd_meta) +
+            (size_t)(slots + 1) * (sizeof(int) + sizeof(struct tamd_grid));
+        char * host = calloc(1, bytes);
+        if (host == NULL) {
+                snprintf(message, size, "could not allocate memory");
+                return TURTLE_RETURN_MEMORY_ERROR;
+        }
+        struct tamd_grid * grids = (struct tamd_grid *)host;
+        struct tamd_stack * st = (struct tamd_stack *)(grids + slots + 1);
+        struct tamd_meta * meta = (struct tamd_meta *)(st + 1);
+        int * tiles = (int *)(meta + 1);
+        int i, n_grids = 0;
+        for (i = 0; i < slots; i++) {
+                tiles[i] = -1;
+                if (s->tile[i] == NULL) continue;
+                if (tamd_map_sync(s->tile[i], &grids[n_grids])) {
+                        free(host);
+                        return -1;
+                }
+                tiles[i] = n_grids++;
+        }
+        st->lat0 = s->latitude_0, st->lon0 = s->longitude_0;
+        st->dlat = s->latitude_delta, st->dlon = s->longitude_delta;
+        st->nlat = s->latitude_n, st->nlon = s->longitude_n;
+        st->tile_first = 0;
+        meta->kind = TAMD_STACK;
+        void * dev;
+        if (tamd_scratch_get(&dev, bytes) || tamd_dev_h2d(dev, host, bytes)) {
+                free(host);
+                return -1;
+        }
+        memset(view, 0, sizeof(*view));
+        view->grids = (const struct tamd_grid *)dev;
+        view->stacks = (const struct tamd_stack *)((char *)dev + ((char *)st - host));
+        view->metas = (const struct tamd_meta *)((char *)dev + ((char *)meta - host));
+        view->tiles = (const int *)((char *)dev + ((char *)tiles - host));
+        view->n_layers = 1;
+        view->geoid = -1;
+        free(host);
+        return 0;
+}
+
+static int stack_elevation_n(struct turtle_stack * stack, long n,
+    const double * latitude, const double * longitude, double * elevation,
+    int * inside, int space, char * message, size_t size)
+{
+        struct tamd_stage st;
+        struct tamd_view view;
+        void *da, *db, *dz, *di;
+        const size_t nb = (size_t)n * sizeof(double);
+        const size_t tables =
+            (size_t)(stack->latitude_n * stack->longitude_n + 2) * 128 + 4096;
+        if (tamd_stage_begin(&st, space, 3 * nb + n * sizeof(int) + tables)) return -1;
+        if (space == TURTLE_AMD_DEVICE) {
+                void * all;
+                tamd_scratch_reset();
+                if (tamd_scratch_get(&all, tables)) return -1;
+                tamd_scratch_reset();
+        }
+        const int rc = stack_view(stack, &view, message, size);
+        if (rc != 0) return rc;
+        if (tamd_stage_in(&st, latitude, nb, &da) || tamd_stage_in(&st, longitude, nb, &db) ||
+            tamd_stage_out(&st, elevation, nb, &dz) ||
+            tamd_stage_out(&st, inside, n * sizeof(int), &di))
+                return -1;
+        if (tamd_k_elevation(view, n, da, db, dz, di)) return -1;
+        if (tamd_stage_fetch(&st, elevation, nb, dz) ||
+            tamd_stage_fetch(&st, inside, n * sizeof(int), di))
+                return -1;
+        return tamd_dev_sync() ? -1 : 0;
+}
+
+enum turtle_return turtle_stack_elevation_n(struct turtle_stack * stack, long n,
+    const double * latitude, const double * longitude, double * elevation,
+    int * inside, int space)
+{
+        TAMD_ERROR_INIT(&turtle_stack_elevation_n);
+        if ((stack == NULL) || (inside == NULL) || (elevation == NULL))
+                return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
+        char message[4200];
+        const int rc = stack_elevation_n(stack, n, latitude, longitude, elevation, inside,
+            space, message, sizeof(message));
+        if (rc < 0) return TAMD_RAISE_DEVICE();
+        if (rc > 0) return TAMD_RAISE((enum turtle_return)rc, "%s", message);
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* Shared by the stack and client scalar calls [ref stack.c:338-361] */
+enum turtle_return tamd_stack_elevation_scalar(struct turtle_stack * stack,
+    turtle_function_t * caller, double latitude, double longitude, double * elevation,
+    int * inside)
+{
+        struct tamd_error error_ = { TURTLE_RETURN_SUCCESS, caller };
+        if (inside != NULL) *inside = 0;
+        double z = 0.;
+        int in = 0;
+        char message[4200];
+        const int rc = stack_elevation_n(stack, 1, &latitude, &longitude, &z, &in,
+            TURTLE_AMD_HOST, message, sizeof(message));
+        if (rc < 0) return TAMD_RAISE_DEVICE();
+        if (rc > 0) return TAMD_RAISE((enum turtle_return)rc, "%s", message);
+        *elevation = in ? z : 0.;
+        if (inside != NULL)
+                *inside = in;
+        else if (!in) /* [ref stack.c:403-411, error.h:86-91] */
+                return TAMD_RAISE(TURTLE_RETURN_PATH_ERROR,
+                    "missing elevation data in `%s'", stack->root);
+        return TURTLE_RETURN_SUCCESS;
+}
+
+enum turtle_return turtle_stack_elevation(struct turtle_stack * stack,
+    double latitude, double longitude, double * elevation, int * inside)
+{
+        return tamd_stack_elevation_scalar(stack,
+            (turtle_function_t *)&turtle_stack_elevation, latitude, longitude, elevation,
+            inside);
+}

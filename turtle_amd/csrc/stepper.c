@@ -1,0 +1,533 @@
+/*
+ * stepper.c -- the layered-topography stepper handle [ref src/turtle/
+ * stepper.c:379-931, stepper.h:45-110].
+ *
+ * The reference keeps linked lists of layers -> (data, offset) metas -> data
+ * sources and walks them per sample on the CPU.  Here the same description is
+ * kept in small host arrays and FLATTENED into POD tables in HBM
+ * (internal.h); every sample, step and trace is then computed by the kernels
+ * of device.hip.  Scalar entry points are the batch ones with n = 1.
+ */
+#include "host.h"
+
+#include <float.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- construction [ref stepper.c:547-600] -------------------------------- */
+
+enum turtle_return turtle_stepper_create(struct turtle_stepper ** stepper)
+{
+        TAMD_ERROR_INIT(&turtle_stepper_create);
+        struct turtle_stepper * s = calloc(1, sizeof(*s));
+        if (s == NULL)
+                return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
+        s->local_range = 1.; /* defaults [ref stepper.c:558-560] */
+        s->slope_factor = 0.4;
+        s->resolution_factor = 1E-02;
+        *stepper = s;
+        return TURTLE_RETURN_SUCCESS;
+}
+
+enum turtle_return turtle_stepper_destroy(struct turtle_stepper ** stepper)
+{
+        if ((stepper == NULL) || (*stepper == NULL)) return TURTLE_RETURN_SUCCESS;
+        struct turtle_stepper * s = *stepper;
+        int i;
+        for (i = 0; i < s->n_data; i++) /* owned clients [ref stepper.c:578-586] */
+                if (s->data[i].client != NULL) turtle_client_destroy(&s->data[i].client);
+        for (i = 0; i < s->n_layers; i++) free(s->layers[i].meta);
+        if ((s->d_tables != NULL) || (s->d_stats != NULL)) tamd_dev_sync();
+        tamd_dev_free(s->d_tables);
+        tamd_dev_free(s->d_stats);
+        free(s->data);
+        free(s->layers);
+        free(s);
+        *stepper = NULL;
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* [ref stepper.c:364-388]: an empty top layer is reused */
+static int push_layer(struct turtle_stepper * s)
+{
+        if ((s->n_layers > 0) && (s->layers[s->n_layers - 1].size == 0)) return 0;
+        if (s->n_layers == s->cap_layers) {
+                const int cap = s->cap_layers ? 2 * s->cap_layers : 4;
+                struct tamd_layer * l = realloc(s->layers, cap * sizeof(*l));
+                if (l == NULL) return 1;
+                s->layers = l, s->cap_layers = cap;
+        }
+        memset(&s->layers[s->n_layers++], 0, sizeof(*s->layers));
+        tamd_geometry_epoch++;
+        return 0;
+}
+
+enum turtle_return turtle_stepper_add_layer(struct turtle_stepper * stepper)
+{
+        TAMD_ERROR_INIT(&turtle_stepper_add_layer);
+        if (push_layer(stepper))
+                return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
+        return TURTLE_RETURN_SUCCESS;
+}
+
+static int push_data(struct turtle_stepper * s, const struct tamd_data * d)
+{
+        if (s->n_data == s->cap_data) {
+                const int cap = s->cap_data ? 2 * s->cap_data : 4;
+                struct tamd_data * p = realloc(s->data, cap * sizeof(*p));
+                if (p == NULL) return -1;
+                s->data = p, s->cap_data = cap;
+        }
+        s->data[s->n_data] = *d;
+        return s->n_data++;
+}
+
+/* [ref stepper.c:390-409]: the first data creates layer 0; metas append to
+ * the top layer */
+static int push_meta(struct turtle_stepper * s, int data, double offset)
+{
+        if ((s->n_layers == 0) && push_layer(s)) return 1;
+        struct tamd_layer * l = &s->layers[s->n_layers - 1];
+        if (l->size == l->capacity) {
+                const int cap = l->capacity ? 2 * l->capacity : 4;
+                struct tamd_layer_meta * m = realloc(l->meta, cap * sizeof(*m));
+                if (m == NULL) return 1;
+                l->meta = m, l->capacity = cap;
+        }
+        l->meta[l->size].data = data;
+        l->meta[l->size].offset = offset;
+        l->size++;
+        tamd_geometry_epoch++;
+        return 0;
+}
+
+/* [ref stepper.c:411-470]: one data per distinct stack; a locked stack gets a
+ * client owned by the stepper */
+enum turtle_return turtle_stepper_add_stack(
+    struct turtle_stepper * stepper, struct turtle_stack * stack, double offset)
+{
+        TAMD_ERROR_INIT(&turtle_stepper_add_stack);
+        int i, data = -1;
+        for (i = 0; i < stepper->n_data; i++)
+                if ((stepper->data[i].kind == TAMD_STACK) && (stepper->data[i].stack == stack))
+                        data = i;
+        if (data < 0) {
+                struct tamd_data d = { TAMD_STACK, NULL, stack, NULL };
+                if (stack->lock != NULL) {
+                        const enum turtle_return rc = turtle_client_create(&d.client, stack);
+                        if (rc != TURTLE_RETURN_SUCCESS) return rc;
+                }
+                data = push_data(stepper, &d);
+                if (data < 0) {
+                        turtle_client_destroy(&d.client);
+                        return TAMD_RAISE(
+                            TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
+                }
+        }
+        if (push_meta(stepper, data, offset))
+                return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* [ref stepper.c:472-509] */
+enum turtle_return turtle_stepper_add_map(
+    struct turtle_stepper * stepper, struct turtle_map * map, double offset)
+{
+        TAMD_ERROR_INIT(&turtle_stepper_add_map);
+        int i, data = -1;
+        for (i = 0; i < stepper->n_data; i++)
+                if ((stepper->data[i].kind == TAMD_MAP) && (stepper->data[i].map == map))
+                        data = i;
+        if (data < 0) {
+                const struct tamd_data d = { TAMD_MAP, map, NULL, NULL };
+                data = push_data(stepper, &d);
+        }
+        if ((data < 0) || push_meta(stepper, data, offset))
+                return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* [ref stepper.c:511-545] */
+enum turtle_return turtle_stepper_add_flat(struct turtle_stepper * stepper, double offset)
+{
+        TAMD_ERROR_INIT(&turtle_stepper_add_flat);
+        int i, data = -1;
+        for (i = 0; i < stepper->n_data; i++)
+                if (stepper->data[i].kind == TAMD_FLAT) data = i;
+        if (data < 0) {
+                const struct tamd_data d = { TAMD_FLAT, NULL, NULL, NULL };
+                data = push_data(stepper, &d);
+        }
+        if ((data < 0) || push_meta(stepper, data, offset))
+                return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* ---- setters/getters [ref stepper.c:617-672] ----------------------------- */
+
+void turtle_stepper_geoid_set(struct turtle_stepper * stepper, struct turtle_map * geoid)
+{
+        stepper->geoid = geoid;
+        tamd_geometry_epoch++;
+}
+
+struct turtle_map * turtle_stepper_geoid_get(const struct turtle_stepper * stepper)
+{
+        return stepper->geoid;
+}
+
+double turtle_stepper_range_get(const struct turtle_stepper * stepper)
+{
+        return stepper->local_range;
+}
+
+void turtle_stepper_range_set(struct turtle_stepper * stepper, double range)
+{
+        stepper->local_range = range; /* recorded only: see turtle_amd.h */
+}
+
+/* nothing is cached between calls, so there is no history to reset */
+void turtle_stepper_reset(struct turtle_stepper * stepper) { (void)stepper; }
+
+double turtle_stepper_slope_get(const struct turtle_stepper * stepper)
+{
+        return stepper->slope_factor;
+}
+
+void turtle_stepper_slope_set(struct turtle_stepper * stepper, double slope)
+{
+        stepper->slope_factor = slope;
+}
+
+double turtle_stepper_resolution_get(const struct turtle_stepper * stepper)
+{
+        return stepper->resolution_factor;
+}
+
+void turtle_stepper_resolution_set(struct turtle_stepper * stepper, double resolution)
+{
+        stepper->resolution_factor = resolution;
+}
+
+/* ---- flattening ---------------------------------------------------------- */
+
+struct grid_list {
+        struct turtle_map ** map;
+        int n, cap;
+};
+
+static int grid_index(struct grid_list * g, struct turtle_map * m)
+{
+        int i;
+        for (i = 0; i < g->n; i++)
+                if (g->map[i] == m) return i;
+        if (g->n == g->cap) {
+                const int cap = g->cap ? 2 * g->cap : 16;
+                struct turtle_map ** p = realloc(g->map, cap * sizeof(*p));
+                if (p == NULL) return -1;
+                g->map = p, g->cap = cap;
+        }
+        g->map[g->n] = m;
+        return g->n++;
+}
+
+/* Returns 0, -1 for a device error (tamd_dev_error has the text), or a
+ * positive enum turtle_return with `message` filled in. */
+int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
+{
+        if (tamd_dev_init()) return -1;
+        if (s->d_stats == NULL) {
+                if (tamd_dev_malloc((void **)&s->d_stats, 8 * sizeof(*s->d_stats))) return -1;
+                if (tamd_dev_zero(s->d_stats, 8 * sizeof(*s->d_stats))) return -1;
+        }
+        s->view.slope = s->slope_factor;
+        s->view.resolution = s->resolution_factor;
+        if ((s->epoch == tamd_geometry_epoch) && (s->d_tables != NULL)) return 0;
+
+        /* make sure every tile of every stack is in memory */
+        int i, j, n_stacks = 0, n_tiles = 0, n_metas = 0;
+        for (i = 0; i < s->n_data; i++) {
+                if (s->data[i].kind != TAMD_STACK) continue;
+                const int rc = tamd_stack_load_all(s->data[i].stack, message, size);
+                if (rc != TURTLE_RETURN_SUCCESS) return rc;
+                n_stacks++;
+                n_tiles += s->data[i].stack->latitude_n * s->data[i].stack->longitude_n;
+        }
+        for (i = 0; i < s->n_layers; i++) n_metas += s->layers[i].size;
+
+        /* unique grids: maps, tiles, geoid */
+        struct grid_list gl = { NULL, 0, 0 };
+        int rc = 0;
+        int * data_src = calloc(s->n_data + 1, sizeof(*data_src));
+        int * tiles = calloc(n_tiles + 1, sizeof(*tiles));
+        struct tamd_stack * stacks = calloc(n_stacks + 1, sizeof(*stacks));
+        if ((data_src == NULL) || (tiles == NULL) || (stacks == NULL)) rc = 1;
+        int stack_count = 0, tile_count = 0;
+        for (i = 0; (rc == 0) && (i < s->n_data); i++) {
+                struct tamd_data * d = &s->data[i];
+                if (d->kind == TAMD_MAP) {
+                        data_src[i] = grid_index(&gl, d->map);
+                        if (data_src[i] < 0) rc = 1;
+                } else if (d->kind == TAMD_STACK) {
+                        struct turtle_stack * st = d->stack;
+                        struct tamd_stack * t = &stacks[stack_count];
+                        t->lat0 = st->latitude_0, t->lon0 = st->longitude_0;
+                        t->dlat = st->latitude_delta, t->dlon = st->longitude_delta;
+                        t->nlat = st->latitude_n, t->nlon = st->longitude_n;
+                        t->tile_first = tile_count;
+                        const int slots = st->latitude_n * st->longitude_n;
+                        for (j = 0; (rc == 0) && (j < slots); j++) {
+                                int g = -1;
+                                if (st->tile[j] != NULL) {
+                                        g = grid_index(&gl, st->tile[j]);
+                                        if (g < 0) rc = 1;
+                                }
+                                tiles[tile_count++] = g;
+                        }
+                        data_src[i] = stack_count++;
+                }
+        }
+        int geoid = -1;
+        if ((rc == 0) && (s->geoid != NULL)) {
+                geoid = grid_index(&gl, s->geoid);
+                if (geoid < 0) rc = 1;
+        }
+        if (rc != 0) {
+                free(gl.map), free(data_src), free(tiles), free(stacks);
+                snprintf(message, size, "could not allocate memory");
+                return TURTLE_RETURN_MEMORY_ERROR;
+        }
+
+        /* one blob: grids | stacks | metas | layer_first | tiles */
+        const size_t o_grids = 0;
+        const size_t o_stacks = o_grids + (size_t)(gl.n + 1) * sizeof(struct tamd_grid);
+        const size_t o_metas = o_stacks + (size_t)(n_stacks + 1) * sizeof(struct tamd_stack);
+        const size_t o_first = o_metas + (size_t)(n_metas + 1) * sizeof(struct tamd_meta);
+        const size_t o_tiles = o_first + (size_t)(s->n_layers + 2) * sizeof(int);
+        const size_t bytes = o_tiles + (size_t)(n_tiles + 1) * sizeof(int);
+        char * host = calloc(1, bytes);
+        if (host == NULL) {
+                free(gl.map), free(data_src), free(tiles), free(stacks);
+                snprintf(message, size, "could not allocate memory");
+                return TURTLE_RETURN_MEMORY_ERROR;
+        }
+        struct tamd_grid * h_grids = (struct tamd_grid *)(host + o_grids);
+        struct tamd_meta * h_metas = (struct tamd_meta *)(host + o_metas);
+        int * h_first = (int *)(host + o_first);
+        int dev_fail = 0;
+        for (i = 0; i < gl.n; i++)
+                if (tamd_map_sync(gl.map[i], &h_grids[i])) dev_fail = 1;
+        memcpy(host + o_stacks, stacks, (size_t)n_stacks * sizeof(*stacks));
+        memcpy(host + o_tiles, tiles, (size_t)n_tiles * sizeof(*tiles));
+        int m = 0;
+        for (i = 0; i < s->n_layers; i++) {
+                h_first[i] = m;
+                /* last added first [ref stepper.c:722-724] */
+                for (j = s->layers[i].size - 1; j >= 0; j--, m++) {
+                        const struct tamd_layer_meta * lm = &s->layers[i].meta[j];
+                        h_metas[m].kind = s->data[lm->data].kind;
+                        h_metas[m].src = data_src[lm->data];
+                        h_metas[m].offset = lm->offset;
+                }
+        }
+        h_first[s->n_layers] = m;
+
+        if (!dev_fail && (bytes > s->d_tables_size)) {
+                tamd_dev_sync();
+                tamd_dev_free(s->d_tables);
+                s->d_tables = NULL, s->d_tables_size = 0;
+                if (tamd_dev_malloc(&s->d_tables, bytes))
+                        dev_fail = 1;
+                else
+                        s->d_tables_size = bytes;
+        }
+        if (!dev_fail && tamd_dev_h2d(s->d_tables, host, bytes)) dev_fail = 1;
+
+        if (!dev_fail) {
+                char * d = s->d_tables;
+                s->view.grids = (const struct tamd_grid *)(d + o_grids);
+                s->view.stacks = (const struct tamd_stack *)(d + o_stacks);
+                s->view.metas = (const struct tamd_meta *)(d + o_metas);
+                s->view.layer_first = (const int *)(d + o_first);
+                s->view.tiles = (const int *)(d + o_tiles);
+                s->view.n_layers = s->n_layers;
+                s->view.geoid = geoid;
+                s->view.mode = TAMD_MODE_GENERIC;
+                if ((s->n_layers == 1) && (n_metas == 1) && (geoid < 0)) {
+                        if (h_metas[0].kind == TAMD_MAP) s->view.mode = TAMD_MODE_ONE_MAP;
+                        if (h_metas[0].kind == TAMD_STACK) s->view.mode = TAMD_MODE_ONE_STACK;
+                }
+                s->epoch = tamd_geometry_epoch;
+        }
+        free(host), free(gl.map), free(data_src), free(tiles), free(stacks);
+        return dev_fail ? -1 : 0;
+}
+
+#define FLATTEN_OR_RETURN(stepper)                                             \
+        do {                                                                   \
+                char message_[4200];                                           \
+                const int rc_ = tamd_stepper_flatten((stepper), message_, sizeof(message_)); \
+                if (rc_ < 0) return TAMD_RAISE_DEVICE();                       \
+                if (rc_ > 0) return TAMD_RAISE((enum turtle_return)rc_, "%s", message_); \
+        } while (0)
+
+/* ---- batch entry points --------------------------------------------------- */
+
+enum turtle_return turtle_stepper_position_n(struct turtle_stepper * stepper, long n,
+    const double * latitude, const double * longitude, const double * height,
+    int layer_index, double * position, int * data_index, int space)
+{
+        TAMD_ERROR_INIT(&turtle_stepper_position_n);
+        if ((layer_index < 0) || (layer_index >= stepper->n_layers))
+                return TAMD_RAISE(TURTLE_RETURN_DOMAIN_ERROR, "no valid data");
+        if ((position == NULL) || (data_index == NULL))
+                return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
+        FLATTEN_OR_RETURN(stepper);
+        struct tamd_stage st;
+        void *dla, *dlo, *dh, *dp, *di;
+        const size_t nb = (size_t)n * sizeof(double);
+        if (tamd_stage_begin(&st, space, 6 * nb + n * sizeof(int)) ||
+            tamd_stage_in(&st, latitude, nb, &dla) || tamd_stage_in(&st, longitude, nb, &dlo) ||
+            tamd_stage_in(&st, height, nb, &dh) ||
+            tamd_stage_in(&st, position, 3 * nb, &dp) || /* untouched rows keep their value */
+            tamd_stage_out(&st, data_index, n * sizeof(int), &di) ||
+            tamd_k_position(stepper->view, n, dla, dlo, dh, layer_index, dp, di) ||
+            tamd_stage_fetch(&st, position, 3 * nb, dp) ||
+            tamd_stage_fetch(&st, data_index, n * sizeof(int), di) || tamd_stage_end(&st))
+                return TAMD_RAISE_DEVICE();
+        return TURTLE_RETURN_SUCCESS;
+}
+
+static enum turtle_return step_n(struct tamd_error * error, struct turtle_stepper * stepper,
+    long n, double * position, const double * direction, double * latitude,
+    double * longitude, double * altitude, double * elevation, double * step, int * index,
+    int flags, int space)
+{
+        struct tamd_error error_ = *error;
+        if ((position == NULL) || (index == NULL))
+                return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
+        if ((flags & TURTLE_AMD_STEP_RESUME) && ((altitude == NULL) || (elevation == NULL)))
+                return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS,
+                    "TURTLE_AMD_STEP_RESUME needs altitude, elevation and index");
+        FLATTEN_OR_RETURN(stepper);
+        struct tamd_stage st;
+        void *dp, *dd, *dla, *dlo, *dal, *del, *dst, *dix;
+        const size_t nb = (size_t)n * sizeof(double);
+        const int resume = (flags & TURTLE_AMD_STEP_RESUME) != 0;
+        if (tamd_stage_begin(&st, space, 12 * nb + 2 * n * sizeof(int)) ||
+            tamd_stage_in(&st, position, 3 * nb, &dp) ||
+            tamd_stage_in(&st, direction, 3 * nb, &dd))
+                return TAMD_RAISE_DEVICE();
+        int bad = 0;
+        if (resume) {
+                bad |= tamd_stage_in(&st, latitude, nb, &dla);
+                bad |= tamd_stage_in(&st, longitude, nb, &dlo);
+                bad |= tamd_stage_in(&st, altitude, nb, &dal);
+                bad |= tamd_stage_in(&st, elevation, 2 * nb, &del);
+                bad |= tamd_stage_in(&st, index, 2 * n * sizeof(int), &dix);
+        } else {
+                bad |= tamd_stage_out(&st, latitude, nb, &dla);
+                bad |= tamd_stage_out(&st, longitude, nb, &dlo);
+                bad |= tamd_stage_out(&st, altitude, nb, &dal);
+                bad |= tamd_stage_out(&st, elevation, 2 * nb, &del);
+                bad |= tamd_stage_out(&st, index, 2 * n * sizeof(int), &dix);
+        }
+        bad |= tamd_stage_out(&st, step, nb, &dst);
+        if (bad || tamd_k_step(stepper->view, n, dp, dd, dla, dlo, dal, del, dst, dix, flags) ||
+            ((direction != NULL) && tamd_stage_fetch(&st, position, 3 * nb, dp)) ||
+            tamd_stage_fetch(&st, latitude, nb, dla) ||
+            tamd_stage_fetch(&st, longitude, nb, dlo) ||
+            tamd_stage_fetch(&st, altitude, nb, dal) ||
+            tamd_stage_fetch(&st, elevation, 2 * nb, del) ||
+            tamd_stage_fetch(&st, step, nb, dst) ||
+            tamd_stage_fetch(&st, index, 2 * n * sizeof(int), dix) || tamd_stage_end(&st))
+                return TAMD_RAISE_DEVICE();
+        return TURTLE_RETURN_SUCCESS;
+}
+
+enum turtle_return turtle_stepper_step_n(struct turtle_stepper * stepper, long n,
+    double * position, const double * direction, double * latitude, double * longitude,
+    double * altitude, double * elevation, double * step, int * index, int flags,
+    int space)
+{
+        TAMD_ERROR_INIT(&turtle_stepper_step_n);
+        return step_n(&error_, stepper, n, position, direction, latitude, longitude,
+            altitude, elevation, step, index, flags, space);
+}
+
+enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long n,
+    double * position, const double * direction, int max_steps, int * index,
+    double * length, int * n_steps, int space)
+{
+        TAMD_ERROR_INIT(&turtle_stepper_trace_n);
+        if ((position == NULL) || (direction == NULL) || (index == NULL))
+                return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
+        FLATTEN_OR_RETURN(stepper);
+        struct tamd_stage st;
+        void *dp, *dd, *dix, *dlen, *dns;
+        const size_t nb = (size_t)n * sizeof(double);
+        if (tamd_stage_begin(&st, space, 7 * nb + 3 * n * sizeof(int)) ||
+            tamd_stage_in(&st, position, 3 * nb, &dp) ||
+            tamd_stage_in(&st, direction, 3 * nb, &dd) ||
+            tamd_stage_out(&st, index, 2 * n * sizeof(int), &dix) ||
+            tamd_stage_out(&st, length, nb, &dlen) ||
+            tamd_stage_out(&st, n_steps, n * sizeof(int), &dns) ||
+            tamd_k_trace(stepper->view, n, dp, dd, max_steps, dix, dlen, dns,
+                stepper->d_stats, stepper->d_stats + 4) ||
+            tamd_stage_fetch(&st, position, 3 * nb, dp) ||
+            tamd_stage_fetch(&st, index, 2 * n * sizeof(int), dix) ||
+            tamd_stage_fetch(&st, length, nb, dlen) ||
+            tamd_stage_fetch(&st, n_steps, n * sizeof(int), dns) || tamd_stage_end(&st))
+                return TAMD_RAISE_DEVICE();
+        return TURTLE_RETURN_SUCCESS;
+}
+
+enum turtle_return turtle_stepper_trace_stats(
+    struct turtle_stepper * stepper, unsigned long long stats[4])
+{
+        TAMD_ERROR_INIT(&turtle_stepper_trace_stats);
+        memset(stats, 0, 4 * sizeof(*stats));
+        if (stepper->d_stats == NULL) return TURTLE_RETURN_SUCCESS;
+        if (tamd_dev_d2h(stats, stepper->d_stats, 4 * sizeof(*stats)))
+                return TAMD_RAISE_DEVICE();
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* ---- scalar entry points: the batch ones with n = 1 ------------------------ */
+
+/* [ref stepper.c:780-875].  Outside every data with index == NULL is the one
+ * case the reference raises [ref stepper.c:751-754, :870-873]. */
+enum turtle_return turtle_stepper_step(struct turtle_stepper * stepper, double * position,
+    const double * direction, double * latitude, double * longitude, double * altitude,
+    double * elevation, double * step, int * index)
+{
+        TAMD_ERROR_INIT(&turtle_stepper_step);
+        int idx[2] = { -1, -1 };
+        const enum turtle_return rc = step_n(&error_, stepper, 1, position, direction,
+            latitude, longitude, altitude, elevation, step, idx, 0, TURTLE_AMD_HOST);
+        if (rc != TURTLE_RETURN_SUCCESS) return rc;
+        if (index != NULL) {
+                index[0] = idx[0], index[1] = idx[1];
+        } else if (idx[0] < 0)
+                return TAMD_RAISE(TURTLE_RETURN_DOMAIN_ERROR, "no valid data");
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* [ref stepper.c:877-931] */
+enum turtle_return turtle_stepper_position(struct turtle_stepper * stepper, double latitude,
+    double longitude, double height, int layer_index, double * position, int * data_index)
+{
+        TAMD_ERROR_INIT(&turtle_stepper_position);
+        if ((layer_index < 0) || (layer_index >= stepper->n_layers))
+                return TAMD_RAISE(TURTLE_RETURN_DOMAIN_ERROR, "no valid data");
+        int di = -1;
+        const enum turtle_return rc = turtle_stepper_position_n(stepper, 1, &latitude,
+            &longitude, &height, layer_index, position, &di, TURTLE_AMD_HOST);
+        if (rc != TURTLE_RETURN_SUCCESS) return rc;
+        if (data_index != NULL)
+                *data_index = di;
+        else if (di < 0)
+                return TAMD_RAISE(TURTLE_RETURN_DOMAIN_ERROR, "no valid data");
+        return TURTLE_RETURN_SUCCESS;
+}
