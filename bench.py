@@ -33,6 +33,20 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 TRACE_KERNEL = "k_trace"
 
 
+def host_cores():
+    """CPU threads this process may really use: the cgroup quota if there is
+    one (a GPU box shows every core of the host but grants a share), else the
+    affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(np.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(nodes, n_rays, seed):
     """The CPU restatement (oracle/, kind "port") on a bounded sample of the
     same workload, all host cores, exact transform (range 0) and the
@@ -43,7 +57,7 @@ def cpu_baseline(nodes, n_rays, seed):
     lat, lon, az, el = synth.uniform_rays(n_rays, (45.0, 46.0), (3.0, 4.0), seed=seed)
     pos, _ = geo.position(lat, lon, 500.0)
     d = O.ecef_from_horizontal(lat, lon, az, el)
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     out = {}
     for tag, rng in (("range0", 0.0), ("range1", 1.0)):
         t0 = time.perf_counter()
@@ -92,7 +106,12 @@ def main():
     tile = TA.Map.load(synth.write_hgt(tmp, 45, 3))
     stepper = TA.Stepper()
     stepper.add_map(tile, 0.0)
-    TA.set_stream(torch.cuda.current_stream())
+    # one non-default stream carries everything: the library's launches, torch's
+    # copies and the timing events (the legacy stream's handle 0 cannot be
+    # handed to a C API that reads NULL as "your own stream")
+    stream = torch.cuda.Stream(device=local)
+    torch.cuda.set_stream(stream)
+    TA.set_stream(stream)
 
     # ---- rays: rank r draws block r of the Philox stream; set-up on the GPU ----
     n = args.rays

@@ -154,7 +154,13 @@ def set_stream(stream=None):
     integer, or None for the library's own stream."""
     handle = None
     if stream is not None:
-        handle = C.c_void_p(getattr(stream, "cuda_stream", stream))
+        raw = int(getattr(stream, "cuda_stream", stream))
+        if raw == 0:
+            raise ValueError(
+                "the legacy default stream has handle 0, which the C API reads as "
+                "'use the library stream': pass a torch.cuda.Stream() and make it "
+                "current with torch.cuda.stream(...)")
+        handle = C.c_void_p(raw)
     _check(lib().turtle_amd_stream_set(handle))
 
 
