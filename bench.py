@@ -98,7 +98,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import turtle_amd as TA
-    from turtle_amd import synth
+    from turtle_amd import sharding, synth
 
     # ---- terrain: the synthetic SRTMGL1 tile, loaded through the C API ----
     nodes = synth.srtm_like_nodes(45, 3)
@@ -115,8 +115,7 @@ def main():
 
     # ---- rays: rank r draws block r of the Philox stream; set-up on the GPU ----
     n = args.rays
-    lat, lon, az, el = synth.uniform_rays(n, (45.0, 46.0), (3.0, 4.0),
-                                          seed=0x5EED2026 + rank)
+    lat, lon, az, el = sharding.rank_rays(n, rank, (45.0, 46.0), (3.0, 4.0))
     dev = torch.device("cuda", local)
     t_lat, t_lon, t_az, t_el = (torch.as_tensor(v, device=dev) for v in (lat, lon, az, el))
     pos0, di = stepper.position(t_lat, t_lon, 500.0)
@@ -127,7 +126,8 @@ def main():
     length = torch.empty(n, dtype=torch.float64, device=dev)
     nsteps = torch.empty(n, dtype=torch.int32, device=dev)
     n_media, n_bins, lmax = 2, 1024, 65536.0
-    tally = torch.zeros(n_media + 1 + n_bins + 1 + 1, dtype=torch.int64, device=dev)
+    t_hits, t_hist, t_steps, t_size = sharding.tally_layout(n_media, n_bins)
+    tally = torch.zeros(t_size, dtype=torch.int64, device=dev)
 
     def one_step():
         pos.copy_(pos0)                      # the trace advances positions in place
@@ -135,11 +135,9 @@ def main():
 
     def reduce_tally():
         tally.zero_()
-        TA.tally(index, length, n_media, n_bins, lmax, tally[: n_media + 1],
-                 tally[n_media + 1: n_media + 1 + n_bins + 1])
-        tally[-1] = nsteps.sum(dtype=torch.int64)
-        if world > 1:
-            dist.all_reduce(tally)           # RCCL, ~8 KB: the only collective
+        TA.tally(index, length, n_media, n_bins, lmax, tally[t_hits], tally[t_hist])
+        tally[t_steps] = nsteps.sum(dtype=torch.int64)
+        sharding.all_reduce_tally(tally, world)   # RCCL, ~8 KB: the only collective
 
     for _ in range(args.warmup):
         one_step()
@@ -167,7 +165,7 @@ def main():
     elapsed = float(t_all.item())
 
     stats = stepper.trace_stats()            # of the last launch on this rank
-    total_steps_per_pass = int(tally[-1].item())   # all ranks (all-reduced)
+    total_steps_per_pass = int(tally[t_steps].item())   # all ranks (all-reduced)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     if rank == 0:
@@ -196,7 +194,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "note": "algorithmic bytes; the kernel is fp64-VALU/latency "
                                  "shaped, see DESIGN.md"},
-            "tally": {"hits": [int(v) for v in tally[: n_media + 1].tolist()]},
+            "tally": {"hits": [int(v) for v in tally[t_hits].tolist()]},
         }
         if not args.no_cpu and world == 1:
             cpu, cores, _ = cpu_baseline(nodes, args.cpu_rays, 0x5EED2026)

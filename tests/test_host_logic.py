@@ -1,0 +1,202 @@
+"""Host-side logic of libturtle_amd that needs no GPU: handles, file ingest,
+tile directory, stepper configuration rules, the error convention.
+Mirrors the CPU-checkable parts of tests/test-turtle.c (test_map :412-513,
+test_io_hgt :1049-1089, test_stack :628-690, test_client :697-775,
+test_stepper defaults :893-901)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import turtle_amd as TA
+from turtle_amd import synth
+
+HAS_GPU = TA.device_count() > 0
+
+
+def test_map_create_meta_node_fill():
+    nodes = np.zeros((201, 201))
+    m = TA.Map.create(shape=(201, 201), x=(495000.0, 497000.0), y=(5066000.0, 5068000.0),
+                      z=(0.0, 1000.0))
+    meta = m.meta()
+    assert (meta["nx"], meta["ny"]) == (201, 201)
+    assert meta["x"] == (495000.0, 497000.0) and meta["y"] == (5066000.0, 5068000.0)
+    assert meta["z"][0] == 0.0 and abs(meta["z"][1] - 1000.0) < 1e-9
+    assert meta["encoding"] == "none" and meta["projection"] is None
+    m.fill(3, 7, 1000.0)
+    m.fill(4, 7, 500.0)
+    x, y, z = m.node(3, 7)
+    assert (x, y, z) == (495000.0 + 3 * 10.0, 5066000.0 + 7 * 10.0, 1000.0)
+    # 16-bit quantisation: round((z-z0)/dz)*dz [ref map.c:41-51]
+    dz = 1000.0 / 65535
+    assert m.node(4, 7)[2] == 0.0 + round(500.0 / dz) * dz
+    with pytest.raises(TA.TurtleError) as e:
+        m.fill(201, 0, 1.0)
+    assert e.value.name == "DOMAIN_ERROR" and "point is outside of map" in str(e.value)
+    with pytest.raises(TA.TurtleError) as e:
+        m.fill(0, 0, 1001.0)
+    assert "elevation is outside of map span" in str(e.value)
+    with pytest.raises(TA.TurtleError) as e:
+        m.node(-1, 0)
+    assert e.value.name == "DOMAIN_ERROR"
+    m.destroy()
+    assert nodes.shape == (201, 201)
+
+
+def test_map_create_rejects_bad_input():
+    with pytest.raises(TA.TurtleError) as e:
+        TA.Map.create(shape=(0, 4))
+    assert e.value.name == "DOMAIN_ERROR" and "invalid input parameter(s)" in str(e.value)
+    with pytest.raises(TA.TurtleError):
+        TA.Map.create(shape=(4, 4), z=(1.0, 1.0))
+
+
+def test_error_message_shape():
+    """"{ <function> [#<code>], <file>:<line> } <text>" [ref error.c:108-138]"""
+    with pytest.raises(TA.TurtleError) as e:
+        TA.Map.load("/nonexistent/N45E003.hgt")
+    assert e.value.name == "PATH_ERROR"
+    assert re.match(r"\{ turtle_map_load \[#10\], .*map\.c:\d+ \} could not open file "
+                    r"`/nonexistent/N45E003.hgt'", str(e.value))
+    with pytest.raises(TA.TurtleError) as e:
+        TA.Map.load("/tmp/whatever.xyz")
+    assert e.value.name == "BAD_EXTENSION" and "unsuported file format `xyz'" in str(e.value)
+    with pytest.raises(TA.TurtleError) as e:
+        TA.Map.load("/tmp/noextension")
+    assert e.value.name == "BAD_EXTENSION" and "missing file extension" in str(e.value)
+
+
+def test_hgt_ingest_decodes_once(tmp_path):
+    """Big-endian, north row first on disk -> native int16, south row first in
+    memory; turtle_map_node sees the same values as the reference's get_z
+    [ref io/hgt.c:127-131]; name parsing [ref io/hgt.c:59-104]."""
+    n = 1201
+    nodes = synth.srtm_like_nodes(45, 3, n)
+    nodes[5, 7] = -32768  # a void: NOT masked by the reference
+    nodes[0, 0], nodes[n - 1, n - 1] = -12, 3210
+    path = os.path.join(tmp_path, "N45E003.SRTMGL3.hgt")
+    open(path, "wb").write(synth.hgt_bytes(nodes))
+    m = TA.Map.load(path)
+    meta = m.meta()
+    assert (meta["nx"], meta["ny"]) == (n, n)
+    assert meta["x"] == (3.0, 4.0) and meta["y"] == (45.0, 46.0)
+    assert meta["z"] == (-32767.0, -32767.0 + 65535)
+    for ix, iy in ((0, 0), (n - 1, n - 1), (7, 5), (600, 17), (1200, 0), (0, 1200)):
+        x, y, z = m.node(ix, iy)
+        assert z == float(nodes[iy, ix])
+        assert x == 3.0 + ix * (1.0 / (n - 1)) and y == 45.0 + iy * (1.0 / (n - 1))
+    m.fill(2, 2, 10.0)  # test-turtle.c:1080-1085 shape
+    assert m.node(2, 2)[2] == 10.0
+    m.destroy()
+    # west/south names and the SRTMGL1 suffix
+    p2 = os.path.join(tmp_path, "S12W077.SRTMGL1.hgt")
+    open(p2, "wb").write(b"\0" * (2 * 3601 * 3601))
+    m = TA.Map.load(p2)
+    meta = m.meta()
+    assert (meta["nx"], meta["x"], meta["y"]) == (3601, (-77.0, -76.0), (-12.0, -11.0))
+    m.destroy()
+    p3 = os.path.join(tmp_path, "N45E003.hgt")
+    open(p3, "wb").write(b"\0" * 100)  # truncated
+    with pytest.raises(TA.TurtleError) as e:
+        TA.Map.load(p3)
+    assert e.value.name == "BAD_FORMAT" and "missing data" in str(e.value)
+    p4 = os.path.join(tmp_path, "X45E003.hgt")
+    open(p4, "wb").write(b"\0" * 100)
+    with pytest.raises(TA.TurtleError) as e:
+        TA.Map.load(p4)
+    assert e.value.name == "BAD_FORMAT" and "invalid hgt filename" in str(e.value)
+
+
+def test_stack_directory_scan(tmp_path):
+    d = os.path.join(tmp_path, "topo")
+    for la, lo in ((45, 2), (46, 2), (45, 3)):
+        synth.write_hgt(d, la, lo, 1201)
+    open(os.path.join(d, "notes.txt"), "w").write("skipped")
+    os.makedirs(os.path.join(d, "subdir"))
+    s = TA.Stack(d, 3)
+    s.clear()  # nothing loaded yet: fine
+    s.destroy()
+    with pytest.raises(TA.TurtleError) as e:
+        TA.Stack(os.path.join(tmp_path, "missing"))
+    assert e.value.name == "PATH_ERROR" and "could not access" in str(e.value)
+    empty = os.path.join(tmp_path, "empty")
+    os.makedirs(empty)
+    s = TA.Stack(empty)
+    s.load()  # an empty stack loads nothing [ref stack.c:260-261]
+    s.destroy()
+
+
+def test_stack_lock_consistency_and_client(tmp_path):
+    import ctypes as C
+    LOCKER = C.CFUNCTYPE(C.c_int)
+    calls = []
+
+    @LOCKER
+    def lock():
+        calls.append("lock")
+        return 0
+
+    d = os.path.join(tmp_path, "topo")
+    synth.write_hgt(d, 45, 3, 1201)
+    with pytest.raises(TA.TurtleError) as e:
+        TA.Stack(d, 0, lock, None)
+    assert e.value.name == "BAD_ADDRESS" and "inconsistent lock & unlock" in str(e.value)
+    L = TA.lib()
+    plain = TA.Stack(d, 0)
+    h = C.c_void_p()
+    rc = L.turtle_client_create(C.byref(h), plain.h)  # [ref client.c:52-55]
+    from turtle_amd import binding as Bn
+    with pytest.raises(TA.TurtleError) as e:
+        Bn._check(rc)
+    assert e.value.name == "BAD_ADDRESS" and "stack has no lock" in str(e.value)
+    plain.destroy()
+    locked = TA.Stack(d, 0, lock, lock)
+    Bn._check(L.turtle_client_create(C.byref(h), locked.h))
+    locked.clear()
+    assert calls == ["lock", "lock"]
+    Bn._check(L.turtle_client_destroy(C.byref(h)))
+    assert h.value is None
+    st = TA.Stepper()
+    st.add_stack(locked, 0.0)  # creates (and later destroys) its own client
+    st.destroy()
+    locked.destroy()
+
+
+def test_stepper_defaults_and_setters():
+    st = TA.Stepper()
+    assert st.range == 1.0 and st.slope == 0.4 and st.resolution == 1e-2
+    st.range, st.slope, st.resolution = 10.0, 1.0, 1e-3
+    assert (st.range, st.slope, st.resolution) == (10.0, 1.0, 1e-3)
+    m = TA.Map.create(shape=(2, 2))
+    st.geoid_set(m)
+    assert TA.lib().turtle_stepper_geoid_get(st.h) == m.h.value
+    st.destroy()
+    m.destroy()
+
+
+def _layer_exists(st, layer):
+    """turtle_stepper_position checks the layer index before any device work
+    [ref stepper.c:883-886]: DOMAIN_ERROR means "no such layer"."""
+    try:
+        st.position_scalar(45.0, 3.0, 0.0, layer)
+    except TA.TurtleError as e:
+        return e.name != "DOMAIN_ERROR" or "no valid data" not in str(e)
+    return True
+
+
+@pytest.mark.skipif(HAS_GPU, reason="uses the no-device failure to stop before compute")
+def test_stepper_layer_rules():
+    m = TA.Map.create(shape=(2, 2))
+    st = TA.Stepper()
+    assert not _layer_exists(st, 0)
+    st.add_flat(0.0)  # the first data creates layer 0 [ref stepper.c:394-396]
+    assert _layer_exists(st, 0) and not _layer_exists(st, 1)
+    st.add_layer()
+    st.add_layer()  # an empty top layer is reused [ref stepper.c:366-368]
+    st.add_map(m, 1.0)
+    st.add_map(m, 2.0)
+    assert _layer_exists(st, 1) and not _layer_exists(st, 2)
+    assert not _layer_exists(st, -1)
+    st.destroy()
+    m.destroy()

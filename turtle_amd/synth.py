@@ -55,12 +55,15 @@ def write_hgt(directory: str, lat0: int, lon0: int, n: int = HGT_N) -> str:
 
 
 def uniform_rays(n: int, lat_range, lon_range, seed: int = 0x5EED2026,
-                 margin: float = 0.1, el_range=(-10.0, -1.0)):
+                 margin: float = 0.1, el_range=(-10.0, -1.0), jump: int = 0):
     """The common ray recipe: origin (lat, lon) uniform inside the
     box shrunk by `margin` of its span, azimuth U[0,360), elevation U[el_range].
-    Counter-based Philox stream, so rank r of a sharded run can draw its own
-    block by seeding (seed, r)."""
-    rng = np.random.Generator(np.random.Philox(seed))
+    Counter-based Philox stream: `jump` = r selects the r-th jumped stream, so
+    rank r of a sharded run draws block r of one global ray array."""
+    bits = np.random.Philox(seed)
+    if jump:
+        bits = bits.jumped(jump)
+    rng = np.random.Generator(bits)
     u = rng.random((4, n))
     dlat = lat_range[1] - lat_range[0]
     dlon = lon_range[1] - lon_range[0]
