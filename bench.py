@@ -109,6 +109,8 @@ def main():
     # one non-default stream carries everything: the library's launches, torch's
     # copies and the timing events (the legacy stream's handle 0 cannot be
     # handed to a C API that reads NULL as "your own stream")
+    if os.environ.get("TURTLE_AMD_MATH"):
+        TA.set_math(os.environ["TURTLE_AMD_MATH"])   # experiments: fast | strict
     stream = torch.cuda.Stream(device=local)
     torch.cuda.set_stream(stream)
     TA.set_stream(stream)
@@ -183,7 +185,8 @@ def main():
             "config": {"workload": "C2: 1M rays/GPU, one 3601x3601 SRTMGL1 tile, "
                                    "trace to first boundary",
                        "rays_per_gpu": n, "max_steps": args.max_steps,
-                       "slope": 0.4, "resolution": 1e-2, "parallelism": f"rays x{world}"},
+                       "slope": 0.4, "resolution": 1e-2, "math": TA.get_math(),
+                       "parallelism": f"rays x{world}"},
             "kernel": {"name": TRACE_KERNEL, "ms": kernel_ms,
                        "steps_per_launch": stats["steps"],
                        "samples_per_launch": stats["samples"],

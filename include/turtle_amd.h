@@ -212,6 +212,22 @@ TURTLE_API enum turtle_return turtle_amd_synchronize(void);
 /* Number of compute units of the selected device (0 if none). */
 TURTLE_API int turtle_amd_compute_units(void);
 
+/* Arithmetic of the trace kernel (turtle_stepper_trace_n) and of
+ * turtle_ecef_to_geodetic(_n), which exposes the same transform for checking.
+ *   STRICT  the reference's expressions in the reference's operand order, no
+ *           FMA contraction, OCML asin/acos/atan2: differs from the x86
+ *           reference only by the last ulp of those three functions.
+ *   FAST    (default) the same algorithm with shared reciprocals, rsqrt-based
+ *           roots, one polynomial arctangent and FMAs: ~3x fewer instructions
+ *           per sample; coordinates differ from STRICT by a few ulp (<= 3e-9 m
+ *           in altitude), path lengths by <= 1e-9 relative.
+ * Both are checked against the reference's golden vectors at the 1e-6 bar.
+ * Every other kernel (elevation, position, step, the other ecef transforms)
+ * is always STRICT. */
+enum turtle_amd_math { TURTLE_AMD_MATH_FAST = 0, TURTLE_AMD_MATH_STRICT = 1 };
+TURTLE_API void turtle_amd_math_set(int mode);
+TURTLE_API int turtle_amd_math_get(void);
+
 /* n independent ECEF transforms; same arithmetic as the scalar forms. */
 TURTLE_API enum turtle_return turtle_ecef_from_geodetic_n(long n,
     const double * latitude, const double * longitude,
@@ -262,6 +278,18 @@ TURTLE_API enum turtle_return turtle_stepper_step_n(
     double * longitude, double * altitude, double * elevation /* [n][2] */,
     double * step, int * index /* [n][2] */, int flags, int space);
 
+/* Flags of turtle_stepper_trace_n. */
+enum turtle_amd_trace_flags {
+        /* On entry index[r][0] holds the medium the ray is in, as returned by
+         * the previous trace/step that left it at this position.  A ray that
+         * has just been put ON a boundary by the bisection sits within 1e-8 m
+         * of it, where re-deriving the medium from a fresh sample is
+         * ill-conditioned; the reference never re-derives it either (its next
+         * step starts from the cached `last` sample [impl stepper.c:708-710,
+         * :826]).  Use this flag to continue rays through successive media. */
+        TURTLE_AMD_TRACE_RESUME = 1
+};
+
 /* The per-ray loop of a Monte-Carlo harness, moved into one kernel: for each
  * ray sample its start point, then step until index[0] differs from its
  * initial value (a boundary was located) or max_steps steps were taken
@@ -272,7 +300,8 @@ TURTLE_API enum turtle_return turtle_stepper_step_n(
 TURTLE_API enum turtle_return turtle_stepper_trace_n(
     struct turtle_stepper * stepper, long n, double * position /* [n][3] */,
     const double * direction /* [n][3] */, int max_steps,
-    int * index /* [n][2] */, double * length, int * n_steps, int space);
+    int * index /* [n][2] */, double * length, int * n_steps, int flags,
+    int space);
 
 /* Totals of the LAST trace_n call on this stepper, accumulated on the device:
  * stats[0] rays, [1] steps, [2] samples (transform + layer lookup), [3]

@@ -138,13 +138,15 @@ class OracleGeometry:
         length = np.empty(n, dtype=np.float64)
         nsteps = np.empty(n, dtype=np.int32)
         samples = C.c_long(0)
+        transforms = C.c_long(0)
         total = lib().orc_trace_n(
             self.ref, C.c_double(slope), C.c_double(resolution),
             C.c_double(local_range), C.c_long(n), _p(pos), _p(dire),
             C.c_int(max_steps), _p(index), _p(length), _p(nsteps),
-            C.c_int(threads), C.byref(samples))
+            C.c_int(threads), C.byref(samples), C.byref(transforms))
         return dict(position=pos, index=index, length=length, n_steps=nsteps,
-                    total_steps=int(total), total_samples=int(samples.value))
+                    total_steps=int(total), total_samples=int(samples.value),
+                    total_transforms=int(transforms.value))
 
     def step(self, position, direction=None, slope=0.4, resolution=1e-2):
         pos = np.array(position, dtype=np.float64, order="C").reshape(-1, 3)

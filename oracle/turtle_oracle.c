@@ -551,7 +551,7 @@ struct trace_job {
         int * index;
         double * length;
         int * n_steps;
-        long steps, samples;
+        long steps, samples, transforms;
 };
 
 static void * trace_worker(void * arg)
@@ -591,13 +591,14 @@ static void * trace_worker(void * arg)
                 job->steps += n;
         }
         job->samples = s.n_samples;
+        job->transforms = s.n_transforms;
         return NULL;
 }
 
 long orc_trace_n(const struct orc_geometry * geometry, double slope,
     double resolution, double range, long n, double * position,
     const double * direction, int max_steps, int * index, double * length,
-    int * n_steps, int threads, long * n_samples)
+    int * n_steps, int threads, long * n_samples, long * n_transforms)
 {
         if (threads < 1) threads = 1;
         if (threads > 1024) threads = 1024;
@@ -621,12 +622,14 @@ long orc_trace_n(const struct orc_geometry * geometry, double slope,
                         pthread_create(&tid[t], NULL, trace_worker, &jobs[t]);
                 for (t = 0; t < threads; t++) pthread_join(tid[t], NULL);
         }
-        long steps = 0, samples = 0;
+        long steps = 0, samples = 0, transforms = 0;
         for (t = 0; t < threads; t++) {
                 steps += jobs[t].steps;
                 samples += jobs[t].samples;
+                transforms += jobs[t].transforms;
         }
         if (n_samples != NULL) *n_samples = samples;
+        if (n_transforms != NULL) *n_transforms = transforms;
         free(jobs);
         free(tid);
         return steps;

@@ -137,7 +137,8 @@ long orc_trace_n(const struct orc_geometry * geometry, double slope,
     double resolution, double range, long n, double * position /*[n][3] io*/,
     const double * direction /*[n][3]*/, int max_steps, int * index /*[n][2]*/,
     double * length /*[n]*/, int * n_steps /*[n]*/, int threads,
-    long * n_samples /* optional: total samples */);
+    long * n_samples /* optional: total samples */,
+    long * n_transforms /* optional: total exact ECEF->geodetic transforms */);
 
 /* One turtle_stepper_step per ray with a fresh stepper history each
  * (direction may be NULL => sample only).  Arrays are per ray; NULL skips. */

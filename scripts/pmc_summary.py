@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSVs: per kernel, mean counter value per dispatch."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+want = sys.argv[2] if len(sys.argv) > 2 else "k_trace"
+acc = defaultdict(lambda: defaultdict(list))
+for path in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(path)):
+        name = row["Kernel_Name"]
+        if want not in name:
+            continue
+        short = name[name.find(want):].split("(")[0]
+        acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for kern, ctr in acc.items():
+    print(f"== {kern}")
+    for c in sorted(ctr):
+        v = ctr[c]
+        print(f"  {c:28s} mean/dispatch {sum(v) / len(v):.6g}   (n={len(v)})")

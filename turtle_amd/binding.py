@@ -16,6 +16,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 HOST, DEVICE = 0, 1
 STEP_RESUME = 1
+TRACE_RESUME = 1
 
 RETURN_NAMES = [
     "SUCCESS", "BAD_ADDRESS", "BAD_EXTENSION", "BAD_FORMAT", "BAD_PROJECTION",
@@ -166,6 +167,16 @@ def set_stream(stream=None):
 
 def synchronize():
     _check(lib().turtle_amd_synchronize())
+
+
+def set_math(mode):
+    """'fast' (default) or 'strict' arithmetic in the trace kernel
+    (enum turtle_amd_math in turtle_amd.h)."""
+    lib().turtle_amd_math_set({"fast": 0, "strict": 1}[mode])
+
+
+def get_math():
+    return "strict" if lib().turtle_amd_math_get() else "fast"
 
 
 # ---- ECEF -------------------------------------------------------------------
@@ -415,17 +426,26 @@ class Stepper:
         out["position"] = pos
         return out
 
-    def trace(self, position, direction, max_steps=100000, want=("length", "n_steps")):
+    def trace(self, position, direction, max_steps=100000, want=("length", "n_steps"),
+              resume_index=None):
+        """turtle_stepper_trace_n.  `resume_index` = the index array a previous
+        trace returned for these rays (TURTLE_AMD_TRACE_RESUME)."""
         sp = _space_of(position, direction)
         pos = _as(position, sp).reshape(-1, 3)
         d = _as(direction, sp).reshape(-1, 3)
         n = pos.shape[0]
-        index = _new((n, 2), sp, np.int32, like=pos)
+        flags = 0
+        if resume_index is not None:
+            flags = TRACE_RESUME
+            index = _as(resume_index, sp, np.int32).reshape(-1, 2)
+            index = index.clone() if _is_torch(index) else index.copy()
+        else:
+            index = _new((n, 2), sp, np.int32, like=pos)
         length = _new((n,), sp, like=pos) if "length" in want else None
         nsteps = _new((n,), sp, np.int32, like=pos) if "n_steps" in want else None
         _check(lib().turtle_stepper_trace_n(self.h, C.c_long(n), _ptr(pos), _ptr(d),
                                             max_steps, _ptr(index), _ptr(length),
-                                            _ptr(nsteps), sp))
+                                            _ptr(nsteps), flags, sp))
         return dict(position=pos, index=index, length=length, n_steps=nsteps)
 
     def trace_into(self, pos, d, index, length, nsteps, max_steps=100000):
@@ -433,7 +453,7 @@ class Stepper:
         the timed call of bench.py."""
         _check(lib().turtle_stepper_trace_n(self.h, C.c_long(pos.shape[0]), _ptr(pos),
                                             _ptr(d), max_steps, _ptr(index), _ptr(length),
-                                            _ptr(nsteps), DEVICE))
+                                            _ptr(nsteps), 0, DEVICE))
 
     def trace_stats(self):
         s = (C.c_ulonglong * 4)()

@@ -32,6 +32,13 @@ enum turtle_return turtle_amd_synchronize(void)
 
 int turtle_amd_compute_units(void) { return tamd_dev_cus(); }
 
+void turtle_amd_math_set(int mode) { tamd_dev_math_set(mode == TURTLE_AMD_MATH_STRICT); }
+
+int turtle_amd_math_get(void)
+{
+        return tamd_dev_math_get() ? TURTLE_AMD_MATH_STRICT : TURTLE_AMD_MATH_FAST;
+}
+
 enum turtle_return turtle_amd_tally_n(long n, const int * index, const double * length,
     int n_media, unsigned long long * hits, int n_bins, double length_max,
     unsigned long long * histogram, int space)

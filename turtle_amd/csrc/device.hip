@@ -131,6 +131,158 @@ __device__ __forceinline__ void d_enu(
         u[0] = cl * cp, u[1] = sl * cp, u[2] = sp;
 }
 
+/* ---- fast-math variant of the transform ----------------------------------
+ *
+ * Same algorithm (Olson 1996, [ref ecef.c:63-130]), leaner arithmetic: the ten
+ * divisions become reciprocals shared between terms, sqrt/rsqrt pairs come
+ * from one v_rsq_f64 seed with two Goldschmidt steps, asin/acos/atan2 become
+ * one first-octant arctangent (3 sectors of half-width pi/16, one division,
+ * degree-8 minimax polynomial in t^2, error < 1e-19), and FMAs are used freely.
+ * Each primitive is good to ~1 ulp, so latitude/longitude/altitude differ from
+ * the strict evaluation by a few ulp (<= 3e-9 m in altitude, <= 1e-13 deg):
+ * the same order as the OCML-vs-glibc differences of the strict path and four
+ * orders of magnitude inside the 1e-6 parity bar.  tests/test_gpu_parity.py
+ * checks both variants against the reference's golden vectors.
+ *
+ * Why it exists: the trace kernel's run time on the 1 M-ray workload is the
+ * latency of its longest ray (11 327 sequential samples), i.e. proportional to
+ * the instruction count of ONE sample, and its throughput on larger batches is
+ * fp64-VALU bound.  This variant needs ~3x fewer instructions per sample. */
+
+__device__ __forceinline__ double f_rcp(double a)
+{
+        double y = __builtin_amdgcn_rcp(a);
+        double e = __builtin_fma(-a, y, 1.);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-a, y, 1.);
+        return __builtin_fma(y, e, y);
+}
+
+/* sqrt(a) and 1/sqrt(a) for a normal, positive a (no denormal scaling) */
+__device__ __forceinline__ void f_sqrt_rsqrt(double a, double & root, double & inverse)
+{
+        const double y = __builtin_amdgcn_rsq(a);
+        double g = a * y, h = 0.5 * y;
+        double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        /* one correction of the root: g += (a - g*g) * h */
+        const double d = __builtin_fma(-g, g, a);
+        root = __builtin_fma(d, h, g);
+        inverse = h + h;
+}
+
+/* atan(y / x) for 0 <= y <= x, x > 0: result in [0, pi/4] */
+__device__ __forceinline__ double f_atan_octant(double y, double x)
+{
+        const bool s1 = y > x * 0.198912367379658;  /* tan(pi/16) */
+        const bool s2 = y > x * 0.6681786379192989; /* tan(3pi/16) */
+        const double tk = s2 ? 1. : (s1 ? 0.41421356237309503 : 0.);
+        const double th = s2 ? 0.7853981633974483 : (s1 ? 0.39269908169872414 : 0.);
+        const double num = __builtin_fma(-x, tk, y);
+        const double den = __builtin_fma(y, tk, x);
+        const double rd = f_rcp(den);
+        double t = num * rd;
+        t = __builtin_fma(__builtin_fma(-den, t, num), rd, t);
+        const double u = t * t;
+        double q = 0.050273062752334695;
+        q = __builtin_fma(q, u, -0.0660516727229625);
+        q = __builtin_fma(q, u, 0.0768988435768423);
+        q = __builtin_fma(q, u, -0.0909085307967067);
+        q = __builtin_fma(q, u, 0.11111110348139375);
+        q = __builtin_fma(q, u, -0.14285714279864764);
+        q = __builtin_fma(q, u, 0.19999999999977505);
+        q = __builtin_fma(q, u, -0.333333333333333);
+        return th + __builtin_fma(t * u, q, t);
+}
+
+/* atan2 for s >= 0, c >= 0 (not both 0): result in [0, pi/2] */
+__device__ __forceinline__ double f_atan2_q1(double s, double c)
+{
+        const bool swap = s > c;
+        const double a = f_atan_octant(swap ? c : s, swap ? s : c);
+        return swap ? 1.5707963267948966 - a : a;
+}
+
+__device__ __forceinline__ double f_atan2(double y, double x)
+{
+        const double ax = fabs(x), ay = fabs(y);
+        double a = f_atan2_q1(ay, ax);
+        if (x < 0.) a = 3.141592653589793 - a;
+        return copysign(a, y);
+}
+
+__device__ __forceinline__ void f_to_geodetic(
+    double x, double y, double z, double & latitude, double & longitude, double & altitude)
+{
+        constexpr double kRad2Deg = 57.29577951308232;
+        const double a = kA;
+        const double e2 = kE * kE;
+        const double a1 = a * e2;
+        const double a2 = a1 * a1;
+        const double a3 = 0.5 * a1 * e2;
+        const double a4 = 2.5 * a2;
+        const double a5 = a1 + a3;
+        const double a6 = 1. - e2;
+
+        if ((x == 0.) && (y == 0.)) { /* [ref ecef.c:77-84] */
+                latitude = (z >= 0.) ? 90. : -90.;
+                longitude = 0.;
+                altitude = fabs(z) - kB;
+                return;
+        }
+
+        longitude = f_atan2(y, x) * kRad2Deg;
+
+        const double zp = fabs(z);
+        const double w2 = __builtin_fma(x, x, y * y);
+        const double z2 = z * z;
+        const double r2 = w2 + z2;
+        double r, ir, w, iw;
+        f_sqrt_rsqrt(r2, r, ir);
+        f_sqrt_rsqrt(w2, w, iw);
+        if (w2 == 0.) w = 0.; /* x*x + y*y underflowed: on the axis to within 1e-162 m */
+        const double ir2 = ir * ir;
+        const double s2 = z2 * ir2;
+        const double c2 = w2 * ir2;
+        const double u0 = a2 * ir;
+        const double v0 = __builtin_fma(-a4, ir, a3);
+
+        double c, s, ss, t1, t2;
+        if (c2 > 0.3) { /* [ref ecef.c:101-107] */
+                s = (zp * ir) * __builtin_fma(c2 * (a1 + u0 + s2 * v0), ir, 1.);
+                ss = s * s;
+                f_sqrt_rsqrt(1. - ss, c, t1);
+        } else { /* [ref ecef.c:108-115] */
+                c = (w * ir) * __builtin_fma(-s2 * (a5 - u0 - c2 * v0), ir, 1.);
+                ss = __builtin_fma(-c, c, 1.);
+                f_sqrt_rsqrt(ss, s, t1);
+        }
+        double la = f_atan2_q1(s, c);
+
+        const double g = __builtin_fma(-e2, ss, 1.); /* [ref ecef.c:117-129] */
+        double sg, isg;
+        f_sqrt_rsqrt(g, sg, isg);
+        const double rg = a * isg;
+        const double rf = a6 * rg;
+        const double u = __builtin_fma(-rg, c, w);
+        const double v = __builtin_fma(-rf, s, zp);
+        const double f = __builtin_fma(c, u, s * v);
+        const double m = __builtin_fma(c, v, -(s * u));
+        const double p = m * f_rcp(__builtin_fma(rf * isg, isg, f));
+        (void)t2;
+        (void)sg;
+        (void)iw;
+
+        la += p;
+        if (z < 0.) la = -la;
+        latitude = la * kRad2Deg;
+        altitude = __builtin_fma(0.5 * m, p, f);
+}
+
 /* ---- one grid --------------------------------------------------------- */
 
 __device__ __forceinline__ double d_node(const tamd_grid & g, int ix, int iy)
@@ -142,12 +294,26 @@ __device__ __forceinline__ double d_node(const tamd_grid & g, int ix, int iy)
 
 /* [ref map.c:229-277]: inclusive upper edge, truncation toward zero, the
  * four-term sum in the reference's operand order. */
+template <bool FAST = false>
 __device__ __forceinline__ bool d_grid_elevation(
     const tamd_grid & g, double x, double y, double & z)
 {
         if (isnan(x) || isnan(y)) return false; /* [ref map.c:233-240] */
-        double hx = (x - g.x0) / g.dx;
-        double hy = (y - g.y0) / g.dy;
+        double hx, hy;
+        if (FAST) {
+                /* reciprocal multiply; within 1e-6 cell of the grid's rim the
+                 * exact quotient decides inside/outside, as in the reference */
+                hx = (x - g.x0) * g.inv_dx;
+                hy = (y - g.y0) * g.inv_dy;
+                const double ex = (double)(g.nx - 1) - 1e-6, ey = (double)(g.ny - 1) - 1e-6;
+                if (!((hx > 1e-6) && (hx < ex) && (hy > 1e-6) && (hy < ey))) {
+                        hx = (x - g.x0) / g.dx;
+                        hy = (y - g.y0) / g.dy;
+                }
+        } else {
+                hx = (x - g.x0) / g.dx;
+                hy = (y - g.y0) / g.dy;
+        }
         if ((hx > g.nx - 1) || (hx < 0) || (hy > g.ny - 1) || (hy < 0))
                 return false; /* [ref map.c:247-255] */
         int ix = (int)hx;
@@ -189,6 +355,7 @@ __device__ __forceinline__ bool d_tile_holds(
  * the directory formula proposes the tile first (O(1)); its neighbours are
  * consulted only when rounding at a seam makes the box test disagree, which
  * reproduces the list scan's answer without the list. */
+template <bool FAST = false>
 __device__ __forceinline__ bool d_stack_elevation(const tamd_view & v,
     const tamd_stack & st, double latitude, double longitude, double & z)
 {
@@ -205,7 +372,7 @@ __device__ __forceinline__ bool d_stack_elevation(const tamd_view & v,
         {
                 const int t = tiles[cy * st.nlon + cx];
                 if ((t >= 0) && d_tile_holds(v.grids[t], latitude, longitude))
-                        return d_grid_elevation(v.grids[t], longitude, latitude, z);
+                        return d_grid_elevation<FAST>(v.grids[t], longitude, latitude, z);
         }
         for (int j = -1; j <= 1; j++) {
                 for (int i = -1; i <= 1; i++) {
@@ -215,7 +382,7 @@ __device__ __forceinline__ bool d_stack_elevation(const tamd_view & v,
                                 continue;
                         const int t = tiles[iy * st.nlon + ix];
                         if ((t >= 0) && d_tile_holds(v.grids[t], latitude, longitude))
-                                return d_grid_elevation(
+                                return d_grid_elevation<FAST>(
                                     v.grids[t], longitude, latitude, z);
                 }
         }
@@ -224,7 +391,7 @@ __device__ __forceinline__ bool d_stack_elevation(const tamd_view & v,
         if (!(fx < st.nlon) || !(fy < st.nlat)) return false;
         const int t = tiles[(int)fy * st.nlon + (int)fx];
         if (t < 0) return false;
-        const bool inside = d_grid_elevation(v.grids[t], longitude, latitude, z);
+        const bool inside = d_grid_elevation<FAST>(v.grids[t], longitude, latitude, z);
         if (!inside) z = 0.;
         return inside;
 }
@@ -237,6 +404,7 @@ struct Sample {
         int m, k;      /* index[0] = medium/layer, index[1] = data */
 };
 
+template <bool FAST = false>
 __device__ __forceinline__ bool d_source_elevation(const tamd_view & v,
     const tamd_meta & mt, double latitude, double longitude, double & z)
 {
@@ -244,19 +412,22 @@ __device__ __forceinline__ bool d_source_elevation(const tamd_view & v,
                 z = 0.;
                 return true;
         } else if (mt.kind == TAMD_MAP) { /* [ref stepper.c:240-241] x=lon, y=lat */
-                return d_grid_elevation(v.grids[mt.src], longitude, latitude, z);
+                return d_grid_elevation<FAST>(v.grids[mt.src], longitude, latitude, z);
         }
-        return d_stack_elevation(v, v.stacks[mt.src], latitude, longitude, z);
+        return d_stack_elevation<FAST>(v, v.stacks[mt.src], latitude, longitude, z);
 }
 
 /* [ref stepper.c:703-756] + check_layer [ref stepper.c:687-701], always with
  * the exact transform (the reference at local_range = 0) and, when a geoid is
  * set, its undulation removed from the altitude [ref stepper.c:37-51]. */
-template <int MODE>
+template <int MODE, bool FAST = false>
 __device__ __forceinline__ void d_sample(
     const tamd_view & v, double x, double y, double z, Sample & s)
 {
-        d_to_geodetic(x, y, z, s.lat, s.lon, s.alt);
+        if (FAST)
+                f_to_geodetic(x, y, z, s.lat, s.lon, s.alt);
+        else
+                d_to_geodetic(x, y, z, s.lat, s.lon, s.alt);
         s.m = -1, s.k = -1;
         s.e0 = -DBL_MAX, s.e1 = DBL_MAX; /* [ref stepper.c:713-716] */
 
@@ -265,8 +436,8 @@ __device__ __forceinline__ void d_sample(
                 const tamd_meta mt = v.metas[0];
                 double elevation;
                 const bool inside = (MODE == TAMD_MODE_ONE_MAP) ?
-                    d_grid_elevation(v.grids[mt.src], s.lon, s.lat, elevation) :
-                    d_stack_elevation(v, v.stacks[mt.src], s.lat, s.lon, elevation);
+                    d_grid_elevation<FAST>(v.grids[mt.src], s.lon, s.lat, elevation) :
+                    d_stack_elevation<FAST>(v, v.stacks[mt.src], s.lat, s.lon, elevation);
                 if (inside) {
                         elevation += mt.offset;
                         s.k = 0;
@@ -284,7 +455,7 @@ __device__ __forceinline__ void d_sample(
         if (v.geoid >= 0) {
                 double undulation;
                 const double lo = (s.lon >= 0) ? s.lon : s.lon + 360.;
-                if (d_grid_elevation(v.grids[v.geoid], lo, s.lat, undulation))
+                if (d_grid_elevation<FAST>(v.grids[v.geoid], lo, s.lat, undulation))
                         s.alt -= undulation;
         }
         for (int layer = 0; layer < v.n_layers; layer++) {
@@ -293,7 +464,7 @@ __device__ __forceinline__ void d_sample(
                 for (int j = v.layer_first[layer]; j < end; j++, data_index++) {
                         const tamd_meta mt = v.metas[j];
                         double elevation;
-                        if (!d_source_elevation(v, mt, s.lat, s.lon, elevation))
+                        if (!d_source_elevation<FAST>(v, mt, s.lat, s.lon, elevation))
                                 continue;
                         elevation += mt.offset; /* [ref stepper.c:737] */
                         s.k = data_index;
@@ -343,13 +514,17 @@ __global__ void k_ecef_from_geodetic(long n, const double * __restrict__ lat,
         }
 }
 
+template <bool FAST>
 __global__ void k_ecef_to_geodetic(long n, const double * __restrict__ ecef,
     double * __restrict__ lat, double * __restrict__ lon, double * __restrict__ alt)
 {
         for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
              r += (long)gridDim.x * blockDim.x) {
                 double la, lo, al;
-                d_to_geodetic(ecef[3 * r], ecef[3 * r + 1], ecef[3 * r + 2], la, lo, al);
+                if (FAST)
+                        f_to_geodetic(ecef[3 * r], ecef[3 * r + 1], ecef[3 * r + 2], la, lo, al);
+                else
+                        d_to_geodetic(ecef[3 * r], ecef[3 * r + 1], ecef[3 * r + 2], la, lo, al);
                 if (lat) lat[r] = la;
                 if (lon) lon[r] = lo;
                 if (alt) alt[r] = al;
@@ -545,18 +720,26 @@ __device__ __forceinline__ ull wave_sum(ull v)
  * expensive part (ECEF->geodetic + layer lookup) is always executed with a
  * full exec mask, and only the cheap bookkeeping diverges.
  *
+ * Every state samples at  q = B + d * t :
+ *   INIT    t = 0                      B = the ray's origin
+ *   STEP    t = ds (tentative length)  B = last accepted position
+ *   BISECT  t = (ds0 + ds1) / 2        B = the tentative position that crossed
+ * and a STEP sample always moves B to q (accepted, or the bisection's origin),
+ * so the per-lane state is B, d, three step scalars, the path length, the
+ * step count and three small integers.  The arithmetic per ray is exactly
+ * that of calling turtle_stepper_step in a loop [ref stepper.c:780-875].
+ *
  * Finished lanes are refilled from a global ray queue: lanes that need a ray
  * are ranked with ballot/mbcnt, and the wave draws kChunk ray ids at a time
  * with one atomic (wave-aggregated), so the queue sees n / 64 atomics.
  *
  * Results do not depend on which lane runs a ray (rays are independent), so
- * the output is deterministic.  Arithmetic per ray is that of calling the
- * reference's turtle_stepper_step in a loop [ref stepper.c:780-875]. */
-template <int MODE>
+ * the output is deterministic. */
+template <int MODE, bool FAST>
 __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
     double * __restrict__ pos, const double * __restrict__ dir, int max_steps,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
-    ull * __restrict__ stats, ull * __restrict__ queue)
+    int flags, ull * __restrict__ stats, ull * __restrict__ queue)
 {
         long pool_next = 0, pool_end = 0; /* wave-uniform */
         bool exhausted = false;            /* wave-uniform */
@@ -564,11 +747,9 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         long ray = -1;
         bool dead = false;
         int state = ST_INIT, count = 0;
-        double px = 0, py = 0, pz = 0, dx = 0, dy = 0, dz = 0, len = 0;
-        double alt = 0, e0 = 0, e1 = 0; /* last accepted sample */
-        int m = -1, k = -1;
-        double bx = 0, by = 0, bz = 0, ds_t = 0, ds0 = 0, ds1 = 0; /* bisection */
-        int bm = -1, bk = -1;
+        double bx = 0, by = 0, bz = 0, dx = 0, dy = 0, dz = 0, len = 0;
+        double ds = 0, ds0 = 0, ds1 = 0;
+        int m = -1, k = -1, bm = -1, bk = -1;
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_capped = 0;
 
         for (;;) {
@@ -600,7 +781,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                         if (need && (rank < avail)) {
                                 ray = pool_next + rank;
-                                px = pos[3 * ray], py = pos[3 * ray + 1], pz = pos[3 * ray + 2];
+                                bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
                                 dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
                                 len = 0., count = 0, state = ST_INIT;
                         }
@@ -609,63 +790,65 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                 if (__ballot(ray >= 0) == 0) break;
 
                 if (ray >= 0) {
-                        /* ---- where does this lane sample next? ---- */
-                        double ds = 0., ds2 = 0.;
-                        double qx = px, qy = py, qz = pz;
-                        if (state == ST_STEP) {
-                                ds = d_step_length(v, alt, e0, e1, m);
-                                qx = px + dx * ds, qy = py + dy * ds, qz = pz + dz * ds;
-                        } else if (state == ST_BISECT) {
-                                ds2 = 0.5 * (ds0 + ds1);
-                                qx = bx + dx * ds2, qy = by + dy * ds2, qz = bz + dz * ds2;
-                        }
+                        /* ---- one sample at q = B + d * t ---- */
+                        double t = 0.;
+                        if (state == ST_STEP) t = ds;
+                        if (state == ST_BISECT) t = 0.5 * (ds0 + ds1);
+                        double qx = bx, qy = by, qz = bz;
+                        if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
+                                qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
 
                         Sample s;
-                        d_sample<MODE>(v, qx, qy, qz, s);
+                        d_sample<MODE, FAST>(v, qx, qy, qz, s);
                         my_samples++;
 
                         /* ---- bookkeeping (cheap, may diverge) ---- */
                         bool done = false, located = false;
-                        if (state == ST_INIT) {
-                                alt = s.alt, e0 = s.e0, e1 = s.e1, m = s.m, k = s.k;
-                                if ((m < 0) || (max_steps <= 0))
-                                        done = true;
-                                else
-                                        state = ST_STEP;
+                        if (state == ST_BISECT) { /* [ref stepper.c:839-860] */
+                                if (s.m == m)
+                                        ds0 = t;
+                                else {
+                                        ds1 = t;
+                                        bm = s.m, bk = s.k;
+                                }
+                                located = !(ds1 - ds0 > 1E-08);
                         } else if (state == ST_STEP) {
-                                if (s.m == m) { /* no boundary: accept the step */
-                                        px = qx, py = qy, pz = qz;
-                                        alt = s.alt, e0 = s.e0, e1 = s.e1, k = s.k;
+                                bx = qx, by = qy, bz = qz;
+                                if (s.m == m) { /* no boundary: the step stands */
                                         len += ds;
+                                        k = s.k;
+                                        ds = d_step_length(v, s.alt, s.e0, s.e1, s.m);
                                         if (++count >= max_steps) {
                                                 done = true;
                                                 my_capped++;
                                         }
                                 } else { /* [ref stepper.c:832-838] */
-                                        bx = qx, by = qy, bz = qz;
-                                        ds_t = ds, ds0 = -ds, ds1 = 0.;
+                                        ds0 = -ds, ds1 = 0.;
                                         bm = s.m, bk = s.k;
                                         state = ST_BISECT;
                                         located = !(ds1 - ds0 > 1E-08);
                                 }
-                        } else { /* [ref stepper.c:839-860] */
-                                if (s.m == m)
-                                        ds0 = ds2;
-                                else {
-                                        ds1 = ds2;
-                                        bm = s.m, bk = s.k;
+                        } else {
+                                m = s.m, k = s.k;
+                                if ((flags & TURTLE_AMD_TRACE_RESUME) && (m >= 0)) {
+                                        /* the caller knows which medium the ray
+                                         * is in; the sample only sizes the step */
+                                        const int given = index[2 * ray];
+                                        if ((given >= 0) && (given <= v.n_layers)) m = given;
                                 }
-                                located = !(ds1 - ds0 > 1E-08);
+                                ds = (m >= 0) ? d_step_length(v, s.alt, s.e0, s.e1, m) : 0.;
+                                state = ST_STEP;
+                                done = (m < 0) || (max_steps <= 0);
                         }
                         if (located) { /* [ref stepper.c:861-863] */
-                                px = bx + dx * ds1, py = by + dy * ds1, pz = bz + dz * ds1;
-                                len += ds_t + ds1;
+                                bx = bx + dx * ds1, by = by + dy * ds1, bz = bz + dz * ds1;
+                                len += ds + ds1;
                                 count++;
                                 m = bm, k = bk;
                                 done = true;
                         }
                         if (done) {
-                                pos[3 * ray] = px, pos[3 * ray + 1] = py, pos[3 * ray + 2] = pz;
+                                pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
                                 index[2 * ray] = m, index[2 * ray + 1] = k;
                                 if (length) length[ray] = len;
                                 if (n_steps) n_steps[ray] = count;
@@ -731,6 +914,7 @@ static int g_device = -1;
 static int g_cus = 0;
 static hipStream_t g_own_stream = nullptr;
 static hipStream_t g_stream = nullptr;
+static int g_math_strict = 0;
 static void * g_scratch = nullptr;
 static size_t g_scratch_size = 0, g_scratch_used = 0;
 
@@ -920,8 +1104,12 @@ extern "C" int tamd_k_ecef_to_geodetic(
 {
         if (tamd_dev_init()) return 1;
         if (n <= 0) return 0;
-        hipLaunchKernelGGL(k_ecef_to_geodetic, dim3(grid_for(n, 256)), dim3(256), 0,
-            g_stream, n, ecef, lat, lon, alt);
+        if (g_math_strict)
+                hipLaunchKernelGGL(k_ecef_to_geodetic<false>, dim3(grid_for(n, 256)),
+                    dim3(256), 0, g_stream, n, ecef, lat, lon, alt);
+        else
+                hipLaunchKernelGGL(k_ecef_to_geodetic<true>, dim3(grid_for(n, 256)),
+                    dim3(256), 0, g_stream, n, ecef, lat, lon, alt);
         LAUNCH_CHECK("k_ecef_to_geodetic");
         return 0;
 }
@@ -1011,35 +1199,43 @@ static int trace_blocks_per_cu(const void * kernel)
         return blocks;
 }
 
+extern "C" void tamd_dev_math_set(int strict) { g_math_strict = strict ? 1 : 0; }
+extern "C" int tamd_dev_math_get(void) { return g_math_strict; }
+
+template <int MODE, bool FAST>
+static int launch_trace(struct tamd_view view, long n, double * pos, const double * dir,
+    int max_steps, int * index, double * length, int * n_steps, int flags, ull * stats,
+    ull * queue)
+{
+        const void * kernel = (const void *)k_trace<MODE, FAST>;
+        long blocks = (long)g_cus * trace_blocks_per_cu(kernel);
+        const long useful = (n + 255) / 256;
+        if (blocks > useful) blocks = useful;
+        hipLaunchKernelGGL((k_trace<MODE, FAST>), dim3((unsigned)blocks), dim3(256), 0,
+            g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, stats,
+            queue);
+        LAUNCH_CHECK("k_trace");
+        return 0;
+}
+
 extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
-    unsigned long long * stats, unsigned long long * queue)
+    int flags, unsigned long long * stats, unsigned long long * queue)
 {
         if (tamd_dev_init()) return 1;
         HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
         HIP_TRY(hipMemsetAsync(queue, 0, sizeof(ull), g_stream));
         if (n <= 0) return 0;
-        const void * kernel = (view.mode == TAMD_MODE_ONE_MAP) ?
-            (const void *)k_trace<TAMD_MODE_ONE_MAP> :
-            ((view.mode == TAMD_MODE_ONE_STACK) ?
-                    (const void *)k_trace<TAMD_MODE_ONE_STACK> :
-                    (const void *)k_trace<TAMD_MODE_GENERIC>);
-        long blocks = (long)g_cus * trace_blocks_per_cu(kernel);
-        const long useful = (n + 255) / 256;
-        if (blocks > useful) blocks = useful;
-        const dim3 grid((unsigned)blocks), block(256);
 #define TRACE_CASE(MODE)                                                       \
-        hipLaunchKernelGGL(k_trace<MODE>, grid, block, 0, g_stream, view, n, pos, dir, \
-            max_steps, index, length, n_steps, stats, queue)
-        if (view.mode == TAMD_MODE_ONE_MAP)
-                TRACE_CASE(TAMD_MODE_ONE_MAP);
-        else if (view.mode == TAMD_MODE_ONE_STACK)
-                TRACE_CASE(TAMD_MODE_ONE_STACK);
-        else
-                TRACE_CASE(TAMD_MODE_GENERIC);
+        (g_math_strict ?                                                       \
+                launch_trace<MODE, false>(view, n, pos, dir, max_steps, index, length, \
+                    n_steps, flags, stats, queue) :                            \
+                launch_trace<MODE, true>(view, n, pos, dir, max_steps, index, length,  \
+                    n_steps, flags, stats, queue))
+        if (view.mode == TAMD_MODE_ONE_MAP) return TRACE_CASE(TAMD_MODE_ONE_MAP);
+        if (view.mode == TAMD_MODE_ONE_STACK) return TRACE_CASE(TAMD_MODE_ONE_STACK);
+        return TRACE_CASE(TAMD_MODE_GENERIC);
 #undef TRACE_CASE
-        LAUNCH_CHECK("k_trace");
-        return 0;
 }
 
 extern "C" int tamd_k_tally(long n, const int * index, const double * length,

@@ -37,6 +37,7 @@ struct tamd_grid {
         int nx, ny;
         double x0, y0, dx, dy;
         double z0, dz;
+        double inv_dx, inv_dy; /* 1/dx, 1/dy: the fast-math kernels multiply */
         int is_signed;
         int pad_;
 };
@@ -94,6 +95,8 @@ int tamd_dev_current(void);
 int tamd_dev_cus(void);
 int tamd_dev_stream_set(void * stream);
 int tamd_dev_sync(void);
+void tamd_dev_math_set(int strict); /* 1: reference-order arithmetic in k_trace */
+int tamd_dev_math_get(void);
 
 int tamd_dev_malloc(void ** ptr, size_t bytes);
 void tamd_dev_free(void * ptr);
@@ -129,7 +132,8 @@ int tamd_k_step(struct tamd_view view, long n, double * pos,
  * queue: 1 x uint64 work counter; both zeroed by the launcher. */
 int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length,
-    int * n_steps, unsigned long long * stats, unsigned long long * queue);
+    int * n_steps, int flags, unsigned long long * stats,
+    unsigned long long * queue);
 int tamd_k_tally(long n, const int * index, const double * length,
     int n_media, unsigned long long * hits, int n_bins, double length_max,
     unsigned long long * histogram);

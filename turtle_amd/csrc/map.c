@@ -213,6 +213,7 @@ int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
                 grid->nx = map->nx, grid->ny = map->ny;
                 grid->x0 = map->x0, grid->y0 = map->y0;
                 grid->dx = map->dx, grid->dy = map->dy;
+                grid->inv_dx = 1. / map->dx, grid->inv_dy = 1. / map->dy;
                 /* int16 codecs return the code itself [ref io/hgt.c:127-131] */
                 grid->z0 = map->is_signed ? 0. : map->z0;
                 grid->dz = map->is_signed ? 1. : map->dz;

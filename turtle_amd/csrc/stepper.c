@@ -458,7 +458,7 @@ enum turtle_return turtle_stepper_step_n(struct turtle_stepper * stepper, long n
 
 enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long n,
     double * position, const double * direction, int max_steps, int * index,
-    double * length, int * n_steps, int space)
+    double * length, int * n_steps, int flags, int space)
 {
         TAMD_ERROR_INIT(&turtle_stepper_trace_n);
         if ((position == NULL) || (direction == NULL) || (index == NULL))
@@ -470,10 +470,12 @@ enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long 
         if (tamd_stage_begin(&st, space, 7 * nb + 3 * n * sizeof(int)) ||
             tamd_stage_in(&st, position, 3 * nb, &dp) ||
             tamd_stage_in(&st, direction, 3 * nb, &dd) ||
-            tamd_stage_out(&st, index, 2 * n * sizeof(int), &dix) ||
+            ((flags & TURTLE_AMD_TRACE_RESUME) ?
+                    tamd_stage_in(&st, index, 2 * n * sizeof(int), &dix) :
+                    tamd_stage_out(&st, index, 2 * n * sizeof(int), &dix)) ||
             tamd_stage_out(&st, length, nb, &dlen) ||
             tamd_stage_out(&st, n_steps, n * sizeof(int), &dns) ||
-            tamd_k_trace(stepper->view, n, dp, dd, max_steps, dix, dlen, dns,
+            tamd_k_trace(stepper->view, n, dp, dd, max_steps, dix, dlen, dns, flags,
                 stepper->d_stats, stepper->d_stats + 4) ||
             tamd_stage_fetch(&st, position, 3 * nb, dp) ||
             tamd_stage_fetch(&st, index, 2 * n * sizeof(int), dix) ||
