@@ -251,16 +251,17 @@ __device__ __forceinline__ void f_to_geodetic(
         const double u0 = a2 * ir;
         const double v0 = __builtin_fma(-a4, ir, a3);
 
-        double c, s, ss, t1, t2;
-        if (c2 > 0.3) { /* [ref ecef.c:101-107] */
-                s = (zp * ir) * __builtin_fma(c2 * (a1 + u0 + s2 * v0), ir, 1.);
-                ss = s * s;
-                f_sqrt_rsqrt(1. - ss, c, t1);
-        } else { /* [ref ecef.c:108-115] */
-                c = (w * ir) * __builtin_fma(-s2 * (a5 - u0 - c2 * v0), ir, 1.);
-                ss = __builtin_fma(-c, c, 1.);
-                f_sqrt_rsqrt(ss, s, t1);
-        }
+        /* [ref ecef.c:101-115] both seeds are cheap; selecting instead of
+         * branching keeps the wave converged whatever the latitudes */
+        const double s_seed = (zp * ir) * __builtin_fma(c2 * (a1 + u0 + s2 * v0), ir, 1.);
+        const double c_seed = (w * ir) * __builtin_fma(-s2 * (a5 - u0 - c2 * v0), ir, 1.);
+        const bool low = c2 > 0.3; /* |latitude| below ~56.8 deg: seed the sine */
+        const double seed = low ? s_seed : c_seed;
+        const double ss = low ? seed * seed : __builtin_fma(-seed, seed, 1.);
+        double other, unused;
+        f_sqrt_rsqrt(low ? 1. - ss : ss, other, unused);
+        const double s = low ? seed : other;
+        const double c = low ? other : seed;
         double la = f_atan2_q1(s, c);
 
         const double g = __builtin_fma(-e2, ss, 1.); /* [ref ecef.c:117-129] */
@@ -273,7 +274,6 @@ __device__ __forceinline__ void f_to_geodetic(
         const double f = __builtin_fma(c, u, s * v);
         const double m = __builtin_fma(c, v, -(s * u));
         const double p = m * f_rcp(__builtin_fma(rf * isg, isg, f));
-        (void)t2;
         (void)sg;
         (void)iw;
 
@@ -294,26 +294,72 @@ __device__ __forceinline__ double d_node(const tamd_grid & g, int ix, int iy)
 
 /* [ref map.c:229-277]: inclusive upper edge, truncation toward zero, the
  * four-term sum in the reference's operand order. */
+/* Last cell a lane looked up: its id and its four raw nodes.  A ray that
+ * creeps along the surface (the long rays that set the run time of a launch)
+ * stays in one 20-30 m cell for tens of steps; re-using the nodes takes the
+ * gather out of its critical path. */
+struct CellCache {
+        unsigned id;     /* iy * nx + ix, or ~0u when empty */
+        unsigned lo, hi; /* (z00 | z10 << 16), (z01 | z11 << 16), raw codes */
+};
+
+/* [ref map.c:229-277], fast-math form.  Differences from the strict form, none
+ * of which changes an elevation by more than ~1e-12 m: (x - x0) is multiplied
+ * by 1/dx instead of divided (except within 1e-6 cell of the rim, where the
+ * exact quotient decides inside/outside as in the reference); the cell index is
+ * clamped instead of special-cased (hx == nx-1 gives ix = nx-2, fx = 1 either
+ * way); the two nodes of a row come from one unaligned 32-bit load. */
+__device__ __forceinline__ bool f_grid_elevation(
+    const tamd_grid & g, double x, double y, double & z, CellCache * cache = nullptr)
+{
+        double hx = (x - g.x0) * g.inv_dx;
+        double hy = (y - g.y0) * g.inv_dy;
+        const double mx = (double)(g.nx - 1), my = (double)(g.ny - 1);
+        if (__builtin_expect(
+                !((hx > 1e-6) && (hx < mx - 1e-6) && (hy > 1e-6) && (hy < my - 1e-6)), 0)) {
+                hx = (x - g.x0) / g.dx;
+                hy = (y - g.y0) / g.dy;
+        }
+        /* NaN compares false: outside, as [ref map.c:233-240] */
+        const bool inside = (hx >= 0.) && (hx <= mx) && (hy >= 0.) && (hy <= my);
+        const int ix = min(max((int)hx, 0), g.nx - 2);
+        const int iy = min(max((int)hy, 0), g.ny - 2);
+        const double fx = hx - (double)ix, fy = hy - (double)iy;
+        const unsigned id = (unsigned)iy * (unsigned)g.nx + (unsigned)ix;
+        unsigned lo, hi;
+        if ((cache != nullptr) && (cache->id == id)) {
+                lo = cache->lo, hi = cache->hi;
+        } else {
+                const uint16_t * p = g.nodes + id;
+                __builtin_memcpy(&lo, p, 4);
+                __builtin_memcpy(&hi, p + g.nx, 4);
+                if (cache != nullptr) cache->id = id, cache->lo = lo, cache->hi = hi;
+        }
+        double z00, z10, z01, z11;
+        if (g.is_signed) {
+                z00 = (double)(int16_t)(lo & 0xffffu), z10 = (double)((int)lo >> 16);
+                z01 = (double)(int16_t)(hi & 0xffffu), z11 = (double)((int)hi >> 16);
+        } else {
+                z00 = (double)(lo & 0xffffu), z10 = (double)(lo >> 16);
+                z01 = (double)(hi & 0xffffu), z11 = (double)(hi >> 16);
+        }
+        z00 = __builtin_fma(z00, g.dz, g.z0), z10 = __builtin_fma(z10, g.dz, g.z0);
+        z01 = __builtin_fma(z01, g.dz, g.z0), z11 = __builtin_fma(z11, g.dz, g.z0);
+        const double gx = 1. - fx, gy = 1. - fy;
+        z = z00 * gx * gy + z01 * gx * fy + z10 * fx * gy + z11 * fx * fy;
+        return inside;
+}
+
+/* [ref map.c:229-277]: inclusive upper edge, truncation toward zero, the
+ * four-term sum in the reference's operand order. */
 template <bool FAST = false>
 __device__ __forceinline__ bool d_grid_elevation(
     const tamd_grid & g, double x, double y, double & z)
 {
+        if (FAST) return f_grid_elevation(g, x, y, z);
         if (isnan(x) || isnan(y)) return false; /* [ref map.c:233-240] */
-        double hx, hy;
-        if (FAST) {
-                /* reciprocal multiply; within 1e-6 cell of the grid's rim the
-                 * exact quotient decides inside/outside, as in the reference */
-                hx = (x - g.x0) * g.inv_dx;
-                hy = (y - g.y0) * g.inv_dy;
-                const double ex = (double)(g.nx - 1) - 1e-6, ey = (double)(g.ny - 1) - 1e-6;
-                if (!((hx > 1e-6) && (hx < ex) && (hy > 1e-6) && (hy < ey))) {
-                        hx = (x - g.x0) / g.dx;
-                        hy = (y - g.y0) / g.dy;
-                }
-        } else {
-                hx = (x - g.x0) / g.dx;
-                hy = (y - g.y0) / g.dy;
-        }
+        double hx = (x - g.x0) / g.dx;
+        double hy = (y - g.y0) / g.dy;
         if ((hx > g.nx - 1) || (hx < 0) || (hy > g.ny - 1) || (hy < 0))
                 return false; /* [ref map.c:247-255] */
         int ix = (int)hx;
@@ -369,29 +415,29 @@ __device__ __forceinline__ bool d_stack_elevation(const tamd_view & v,
         const int cx = min(max((int)fx, 0), st.nlon - 1);
         const int cy = min(max((int)fy, 0), st.nlat - 1);
         const int * tiles = v.tiles + st.tile_first;
-        {
-                const int t = tiles[cy * st.nlon + cx];
-                if ((t >= 0) && d_tile_holds(v.grids[t], latitude, longitude))
-                        return d_grid_elevation<FAST>(v.grids[t], longitude, latitude, z);
-        }
-        for (int j = -1; j <= 1; j++) {
-                for (int i = -1; i <= 1; i++) {
-                        if ((i == 0) && (j == 0)) continue;
-                        const int ix = cx + i, iy = cy + j;
-                        if ((ix < 0) || (ix >= st.nlon) || (iy < 0) || (iy >= st.nlat))
-                                continue;
-                        const int t = tiles[iy * st.nlon + ix];
-                        if ((t >= 0) && d_tile_holds(v.grids[t], latitude, longitude))
-                                return d_grid_elevation<FAST>(
-                                    v.grids[t], longitude, latitude, z);
+        int tile = tiles[cy * st.nlon + cx];
+        if ((tile < 0) || !d_tile_holds(v.grids[tile], latitude, longitude)) {
+                /* rare: a seam, the rim, or a hole in the mosaic */
+                tile = -1;
+                for (int j = -1; (j <= 1) && (tile < 0); j++) {
+                        for (int i = -1; (i <= 1) && (tile < 0); i++) {
+                                const int ix = cx + i, iy = cy + j;
+                                if (((i == 0) && (j == 0)) || (ix < 0) || (ix >= st.nlon) ||
+                                    (iy < 0) || (iy >= st.nlat))
+                                        continue;
+                                const int t = tiles[iy * st.nlon + ix];
+                                if ((t >= 0) && d_tile_holds(v.grids[t], latitude, longitude))
+                                        tile = t;
+                        }
+                }
+                if (tile < 0) { /* [ref stack.c:413-424] */
+                        if ((longitude < st.lon0) || (latitude < st.lat0)) return false;
+                        if (!(fx < st.nlon) || !(fy < st.nlat)) return false;
+                        tile = tiles[(int)fy * st.nlon + (int)fx];
+                        if (tile < 0) return false;
                 }
         }
-        /* [ref stack.c:413-424] */
-        if ((longitude < st.lon0) || (latitude < st.lat0)) return false;
-        if (!(fx < st.nlon) || !(fy < st.nlat)) return false;
-        const int t = tiles[(int)fy * st.nlon + (int)fx];
-        if (t < 0) return false;
-        const bool inside = d_grid_elevation<FAST>(v.grids[t], longitude, latitude, z);
+        const bool inside = d_grid_elevation<FAST>(v.grids[tile], longitude, latitude, z);
         if (!inside) z = 0.;
         return inside;
 }
@@ -420,9 +466,27 @@ __device__ __forceinline__ bool d_source_elevation(const tamd_view & v,
 /* [ref stepper.c:703-756] + check_layer [ref stepper.c:687-701], always with
  * the exact transform (the reference at local_range = 0) and, when a geoid is
  * set, its undulation removed from the altitude [ref stepper.c:37-51]. */
+/* Descriptors of the single data source of the one-map / one-stack modes,
+ * read ONCE per kernel (they are wave-uniform: SGPRs) instead of per sample. */
+struct OneCtx {
+        tamd_grid grid;
+        tamd_stack stack;
+        double offset;
+};
+
+template <int MODE>
+__device__ __forceinline__ void d_load_ctx(const tamd_view & v, OneCtx & c)
+{
+        if (MODE == TAMD_MODE_GENERIC) return;
+        const tamd_meta mt = v.metas[0];
+        c.offset = mt.offset;
+        if (MODE == TAMD_MODE_ONE_MAP) c.grid = v.grids[mt.src];
+        if (MODE == TAMD_MODE_ONE_STACK) c.stack = v.stacks[mt.src];
+}
+
 template <int MODE, bool FAST = false>
-__device__ __forceinline__ void d_sample(
-    const tamd_view & v, double x, double y, double z, Sample & s)
+__device__ __forceinline__ void d_sample(const tamd_view & v, const OneCtx & ctx, double x,
+    double y, double z, Sample & s, CellCache * cache = nullptr)
 {
         if (FAST)
                 f_to_geodetic(x, y, z, s.lat, s.lon, s.alt);
@@ -433,13 +497,16 @@ __device__ __forceinline__ void d_sample(
 
         if (MODE != TAMD_MODE_GENERIC) {
                 /* one layer holding one data: no loops, no geoid */
-                const tamd_meta mt = v.metas[0];
                 double elevation;
-                const bool inside = (MODE == TAMD_MODE_ONE_MAP) ?
-                    d_grid_elevation<FAST>(v.grids[mt.src], s.lon, s.lat, elevation) :
-                    d_stack_elevation<FAST>(v, v.stacks[mt.src], s.lat, s.lon, elevation);
+                bool inside;
+                if (MODE == TAMD_MODE_ONE_MAP)
+                        inside = FAST ?
+                            f_grid_elevation(ctx.grid, s.lon, s.lat, elevation, cache) :
+                            d_grid_elevation<false>(ctx.grid, s.lon, s.lat, elevation);
+                else
+                        inside = d_stack_elevation<FAST>(v, ctx.stack, s.lat, s.lon, elevation);
                 if (inside) {
-                        elevation += mt.offset;
+                        elevation += ctx.offset;
                         s.k = 0;
                         if (elevation >= s.alt) {
                                 s.m = 0;
@@ -641,6 +708,8 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
     double * __restrict__ elev, double * __restrict__ step, int * __restrict__ index,
     int flags)
 {
+        OneCtx ctx;
+        d_load_ctx<MODE>(v, ctx);
         for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
              r += (long)gridDim.x * blockDim.x) {
                 double px = pos[3 * r], py = pos[3 * r + 1], pz = pos[3 * r + 2];
@@ -653,7 +722,7 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                         s.m = index[2 * r], s.k = index[2 * r + 1];
                         if (s.m < 0) s.e0 = s.e1 = 0.;
                 } else
-                        d_sample<MODE>(v, px, py, pz, s);
+                        d_sample<MODE>(v, ctx, px, py, pz, s);
 
                 double ds = 0.;
                 if (s.m >= 0) {
@@ -663,13 +732,13 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                                              dz = dir[3 * r + 2];
                                 px += dx * ds, py += dy * ds, pz += dz * ds;
                                 const int medium0 = s.m;
-                                d_sample<MODE>(v, px, py, pz, s);
+                                d_sample<MODE>(v, ctx, px, py, pz, s);
                                 if (s.m != medium0) { /* [ref stepper.c:832-864] */
                                         double ds0 = -ds, ds1 = 0.;
                                         while (ds1 - ds0 > 1E-08) {
                                                 const double ds2 = 0.5 * (ds0 + ds1);
                                                 Sample s2;
-                                                d_sample<MODE>(v, px + dx * ds2,
+                                                d_sample<MODE>(v, ctx, px + dx * ds2,
                                                     py + dy * ds2, pz + dz * ds2, s2);
                                                 if (s2.m == medium0)
                                                         ds0 = ds2;
@@ -743,6 +812,9 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
 {
         long pool_next = 0, pool_end = 0; /* wave-uniform */
         bool exhausted = false;            /* wave-uniform */
+        OneCtx ctx;
+        d_load_ctx<MODE>(v, ctx);
+        CellCache cell = { ~0u, 0u, 0u };
 
         long ray = -1;
         bool dead = false;
@@ -799,7 +871,8 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
 
                         Sample s;
-                        d_sample<MODE, FAST>(v, qx, qy, qz, s);
+                        d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
+                            (FAST && (MODE == TAMD_MODE_ONE_MAP)) ? &cell : nullptr);
                         my_samples++;
 
                         /* ---- bookkeeping (cheap, may diverge) ---- */
