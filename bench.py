@@ -47,14 +47,36 @@ def host_cores():
     return n
 
 
-def cpu_baseline(nodes, n_rays, seed):
+WORKLOADS = {
+    # name: (tiles (lat0, lon0, nlat, nlon), through a stack?, default rays/GPU, text)
+    "c2": ((45, 3, 1, 1), False, 1_000_000,
+           "C2: 1M rays/GPU, one 3601x3601 SRTMGL1 tile, trace to first boundary"),
+    "c3": ((45, 3, 4, 4), True, 10_000_000,
+           "C3: 10M rays/GPU, 4x4 mosaic of 3601x3601 tiles through a stack (all "
+           "tiles resident in HBM), trace to first boundary"),
+}
+
+
+def cpu_baseline(tiles, use_stack, n_rays, seed):
     """The CPU restatement (oracle/, kind "port") on a bounded sample of the
     same workload, all host cores, exact transform (range 0) and the
     reference's default local-linear approximation (range 1)."""
     from oracle import ffi as O
-    geo = O.OracleGeometry(grids=[O.hgt_grid(45, 3, nodes)], layers=[[(O.MAP, 0, 0.0)]])
     from turtle_amd import synth
-    lat, lon, az, el = synth.uniform_rays(n_rays, (45.0, 46.0), (3.0, 4.0), seed=seed)
+    lat0, lon0, nlat, nlon = tiles
+    grids, table = [], []
+    for i in range(nlat):
+        for j in range(nlon):
+            table.append(len(grids))
+            grids.append(O.hgt_grid(lat0 + i, lon0 + j, synth.srtm_like_nodes(lat0 + i, lon0 + j)))
+    if use_stack:
+        stack = dict(lat0=float(lat0), lon0=float(lon0), dlat=1.0, dlon=1.0, nlat=nlat,
+                     nlon=nlon, tile=np.array(table, dtype=np.int32))
+        geo = O.OracleGeometry(grids=grids, stacks=[stack], layers=[[(O.STACK, 0, 0.0)]])
+    else:
+        geo = O.OracleGeometry(grids=grids, layers=[[(O.MAP, 0, 0.0)]])
+    lat, lon, az, el = synth.uniform_rays(
+        n_rays, (float(lat0), float(lat0 + nlat)), (float(lon0), float(lon0 + nlon)), seed=seed)
     pos, _ = geo.position(lat, lon, 500.0)
     d = O.ecef_from_horizontal(lat, lon, az, el)
     cores = host_cores()
@@ -77,7 +99,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rays", type=int, default=1_000_000, help="rays per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--rays", type=int, default=0, help="rays per GPU (0 = the workload's)")
     ap.add_argument("--max-steps", type=int, default=100_000)
     ap.add_argument("--cpu-rays", type=int, default=200_000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -100,12 +123,21 @@ def main():
     import turtle_amd as TA
     from turtle_amd import sharding, synth
 
-    # ---- terrain: the synthetic SRTMGL1 tile, loaded through the C API ----
-    nodes = synth.srtm_like_nodes(45, 3)
+    # ---- terrain: synthetic SRTMGL1 tile(s), loaded through the C API ----
+    tiles, use_stack, default_rays, workload_text = WORKLOADS[args.workload]
+    lat0, lon0, nlat, nlon = tiles
+    lat_range, lon_range = (float(lat0), float(lat0 + nlat)), (float(lon0), float(lon0 + nlon))
     tmp = tempfile.mkdtemp(prefix=f"turtle_bench_{rank}_")
-    tile = TA.Map.load(synth.write_hgt(tmp, 45, 3))
+    for i in range(nlat):
+        for j in range(nlon):
+            synth.write_hgt(tmp, lat0 + i, lon0 + j)
     stepper = TA.Stepper()
-    stepper.add_map(tile, 0.0)
+    if use_stack:
+        terrain = TA.Stack(tmp, 0)
+        stepper.add_stack(terrain, 0.0)
+    else:
+        terrain = TA.Map.load(os.path.join(tmp, synth.hgt_name(lat0, lon0)))
+        stepper.add_map(terrain, 0.0)
     # one non-default stream carries everything: the library's launches, torch's
     # copies and the timing events (the legacy stream's handle 0 cannot be
     # handed to a C API that reads NULL as "your own stream")
@@ -116,8 +148,8 @@ def main():
     TA.set_stream(stream)
 
     # ---- rays: rank r draws block r of the Philox stream; set-up on the GPU ----
-    n = args.rays
-    lat, lon, az, el = sharding.rank_rays(n, rank, (45.0, 46.0), (3.0, 4.0))
+    n = args.rays or default_rays
+    lat, lon, az, el = sharding.rank_rays(n, rank, lat_range, lon_range)
     dev = torch.device("cuda", local)
     t_lat, t_lon, t_az, t_el = (torch.as_tensor(v, device=dev) for v in (lat, lon, az, el))
     pos0, di = stepper.position(t_lat, t_lon, 500.0)
@@ -182,9 +214,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: 1M rays/GPU, one 3601x3601 SRTMGL1 tile, "
-                                   "trace to first boundary",
-                       "rays_per_gpu": n, "max_steps": args.max_steps,
+            "config": {"workload": workload_text, "rays_per_gpu": n, "max_steps": args.max_steps,
                        "slope": 0.4, "resolution": 1e-2, "math": TA.get_math(),
                        "parallelism": f"rays x{world}"},
             "kernel": {"name": TRACE_KERNEL, "ms": kernel_ms,
@@ -200,7 +230,7 @@ def main():
             "tally": {"hits": [int(v) for v in tally[t_hits].tolist()]},
         }
         if not args.no_cpu and world == 1:
-            cpu, cores, _ = cpu_baseline(nodes, args.cpu_rays, 0x5EED2026)
+            cpu, cores, _ = cpu_baseline(tiles, use_stack, args.cpu_rays, 0x5EED2026)
             line["cpu_baseline"] = {
                 "value": cpu["range0"], "unit": "ray-steps/s", "cores": cores,
                 "kind": "port",
@@ -211,7 +241,9 @@ def main():
         print(json.dumps(line), flush=True)
 
     stepper.destroy()
-    tile.destroy()
+    terrain.destroy()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -442,6 +442,64 @@ __device__ __forceinline__ bool d_stack_elevation(const tamd_view & v,
         return inside;
 }
 
+/* Fast-math lookup in a `regular` stack (see struct tamd_stack): interior
+ * points take the tile by the directory formula and read its nodes through one
+ * pointer; anything within 1e-6 cell of a tile seam or of the directory's rim,
+ * and any irregular stack, goes through the general routine above, which
+ * decides seams and edges exactly as the reference does. */
+__device__ __forceinline__ bool f_stack_elevation(const tamd_view & v,
+    const tamd_stack & st, double latitude, double longitude, double & z,
+    CellCache * cache)
+{
+        if (st.regular) {
+                const tamd_grid & p = st.proto;
+                const double fx = (longitude - st.lon0) / st.dlon;
+                const double fy = (latitude - st.lat0) / st.dlat;
+                const bool in_dir =
+                    (fx > 0.) && (fx < (double)st.nlon) && (fy > 0.) && (fy < (double)st.nlat);
+                const int tx = in_dir ? (int)fx : 0, ty = in_dir ? (int)fy : 0;
+                const double x0 = st.lon0 + tx * st.dlon, y0 = st.lat0 + ty * st.dlat;
+                const double hx = (longitude - x0) * p.inv_dx;
+                const double hy = (latitude - y0) * p.inv_dy;
+                const double mx = (double)(p.nx - 1) - 1e-6, my = (double)(p.ny - 1) - 1e-6;
+                const bool interior =
+                    in_dir && (hx > 1e-6) && (hx < mx) && (hy > 1e-6) && (hy < my);
+                const int slot = ty * st.nlon + tx;
+                const uint16_t * nodes =
+                    interior ? v.slot_nodes[st.nodes_first + slot] : nullptr;
+                if (nodes != nullptr) {
+                        const int ix = (int)hx, iy = (int)hy;
+                        const double fxc = hx - (double)ix, fyc = hy - (double)iy;
+                        const unsigned cell = (unsigned)iy * (unsigned)p.nx + (unsigned)ix;
+                        const unsigned id = ((unsigned)slot << 24) | cell;
+                        unsigned lo, hi;
+                        if ((cache != nullptr) && (cache->id == id)) {
+                                lo = cache->lo, hi = cache->hi;
+                        } else {
+                                const uint16_t * q = nodes + cell;
+                                __builtin_memcpy(&lo, q, 4);
+                                __builtin_memcpy(&hi, q + p.nx, 4);
+                                if (cache != nullptr)
+                                        cache->id = id, cache->lo = lo, cache->hi = hi;
+                        }
+                        double z00, z10, z01, z11;
+                        if (p.is_signed) {
+                                z00 = (double)(int16_t)(lo & 0xffffu), z10 = (double)((int)lo >> 16);
+                                z01 = (double)(int16_t)(hi & 0xffffu), z11 = (double)((int)hi >> 16);
+                        } else {
+                                z00 = (double)(lo & 0xffffu), z10 = (double)(lo >> 16);
+                                z01 = (double)(hi & 0xffffu), z11 = (double)(hi >> 16);
+                        }
+                        z00 = __builtin_fma(z00, p.dz, p.z0), z10 = __builtin_fma(z10, p.dz, p.z0);
+                        z01 = __builtin_fma(z01, p.dz, p.z0), z11 = __builtin_fma(z11, p.dz, p.z0);
+                        const double gx = 1. - fxc, gy = 1. - fyc;
+                        z = z00 * gx * gy + z01 * gx * fyc + z10 * fxc * gy + z11 * fxc * fyc;
+                        return true;
+                }
+        }
+        return d_stack_elevation<true>(v, st, latitude, longitude, z);
+}
+
 /* ---- layered sample ---------------------------------------------------- */
 
 struct Sample {
@@ -504,7 +562,9 @@ __device__ __forceinline__ void d_sample(const tamd_view & v, const OneCtx & ctx
                             f_grid_elevation(ctx.grid, s.lon, s.lat, elevation, cache) :
                             d_grid_elevation<false>(ctx.grid, s.lon, s.lat, elevation);
                 else
-                        inside = d_stack_elevation<FAST>(v, ctx.stack, s.lat, s.lon, elevation);
+                        inside = FAST ?
+                            f_stack_elevation(v, ctx.stack, s.lat, s.lon, elevation, cache) :
+                            d_stack_elevation<false>(v, ctx.stack, s.lat, s.lon, elevation);
                 if (inside) {
                         elevation += ctx.offset;
                         s.k = 0;
@@ -872,7 +932,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
 
                         Sample s;
                         d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
-                            (FAST && (MODE == TAMD_MODE_ONE_MAP)) ? &cell : nullptr);
+                            (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr);
                         my_samples++;
 
                         /* ---- bookkeeping (cheap, may diverge) ---- */
@@ -1300,7 +1360,7 @@ extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
         HIP_TRY(hipMemsetAsync(queue, 0, sizeof(ull), g_stream));
         if (n <= 0) return 0;
 #define TRACE_CASE(MODE)                                                       \
-        (g_math_strict ?                                                       \
+        ((g_math_strict || !view.fast_ok) ?                                                       \
                 launch_trace<MODE, false>(view, n, pos, dir, max_steps, index, length, \
                     n_steps, flags, stats, queue) :                            \
                 launch_trace<MODE, true>(view, n, pos, dir, max_steps, index, length,  \

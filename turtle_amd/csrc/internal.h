@@ -48,7 +48,15 @@ struct tamd_stack {
         double lat0, lon0, dlat, dlon;
         int nlat, nlon;
         int tile_first; /* offset into the tiles[] table: grid index or -1 */
-        int pad_;
+        /* `regular`: every tile present has the same shape and encoding (nx,
+         * ny, dx, dy, z0, dz, sign) and sits exactly on the lattice (x0 ==
+         * lon0 + ix*dlon, y0 == lat0 + iy*dlat), as SRTM/ASTER tiles do.  The
+         * fast-math kernels then need one pointer per tile (slot_nodes[
+         * nodes_first + slot], NULL for a missing tile) instead of a whole
+         * per-lane grid descriptor; `proto` holds the shared shape. */
+        int regular;
+        int nodes_first, pad_;
+        struct tamd_grid proto;
 };
 
 enum tamd_kind { TAMD_FLAT = 0, TAMD_MAP = 1, TAMD_STACK = 2 };
@@ -73,13 +81,14 @@ struct tamd_view {
         const struct tamd_grid * grids;
         const struct tamd_stack * stacks;
         const int * tiles;
+        const uint16_t * const * slot_nodes; /* see tamd_stack.regular */
         const struct tamd_meta * metas;
         const int * layer_first; /* n_layers + 1 offsets into metas */
         int n_layers;
         int geoid; /* grid index or -1 */
         double slope, resolution;
         int mode; /* enum tamd_mode */
-        int pad_;
+        int fast_ok; /* every grid has nx, ny >= 2: the clamped fast lookup applies */
 };
 
 /* ------------------------------------------------------------------------ */

@@ -299,13 +299,15 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
                 return TURTLE_RETURN_MEMORY_ERROR;
         }
 
-        /* one blob: grids | stacks | metas | layer_first | tiles */
+        /* one blob: grids | stacks | metas | layer_first | tiles | slot_nodes */
         const size_t o_grids = 0;
         const size_t o_stacks = o_grids + (size_t)(gl.n + 1) * sizeof(struct tamd_grid);
         const size_t o_metas = o_stacks + (size_t)(n_stacks + 1) * sizeof(struct tamd_stack);
         const size_t o_first = o_metas + (size_t)(n_metas + 1) * sizeof(struct tamd_meta);
         const size_t o_tiles = o_first + (size_t)(s->n_layers + 2) * sizeof(int);
-        const size_t bytes = o_tiles + (size_t)(n_tiles + 1) * sizeof(int);
+        const size_t o_nodes =
+            (o_tiles + (size_t)(n_tiles + 1) * sizeof(int) + 15) & ~(size_t)15;
+        const size_t bytes = o_nodes + (size_t)(n_tiles + 1) * sizeof(void *);
         char * host = calloc(1, bytes);
         if (host == NULL) {
                 free(gl.map), free(data_src), free(tiles), free(stacks);
@@ -318,6 +320,34 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
         int dev_fail = 0;
         for (i = 0; i < gl.n; i++)
                 if (tamd_map_sync(gl.map[i], &h_grids[i])) dev_fail = 1;
+        /* regular stacks: shared tile shape + one node pointer per slot */
+        const uint16_t ** h_nodes = (const uint16_t **)(host + o_nodes);
+        int fast_ok = 1;
+        for (i = 0; i < gl.n; i++)
+                if ((h_grids[i].nx < 2) || (h_grids[i].ny < 2)) fast_ok = 0;
+        for (i = 0; i < n_stacks; i++) {
+                struct tamd_stack * t = &stacks[i];
+                const int slots = t->nlat * t->nlon;
+                const struct tamd_grid * proto = NULL;
+                int regular = (slots > 0) && (slots <= 255);
+                t->nodes_first = t->tile_first;
+                for (j = 0; j < slots; j++) {
+                        const int g = tiles[t->tile_first + j];
+                        h_nodes[t->nodes_first + j] = (g >= 0) ? h_grids[g].nodes : NULL;
+                        if (g < 0) continue;
+                        const struct tamd_grid * q = &h_grids[g];
+                        if (proto == NULL) proto = q;
+                        if ((q->nx != proto->nx) || (q->ny != proto->ny) ||
+                            (q->dx != proto->dx) || (q->dy != proto->dy) ||
+                            (q->z0 != proto->z0) || (q->dz != proto->dz) ||
+                            (q->is_signed != proto->is_signed) ||
+                            (q->x0 != t->lon0 + (j % t->nlon) * t->dlon) ||
+                            (q->y0 != t->lat0 + (j / t->nlon) * t->dlat))
+                                regular = 0;
+                }
+                t->regular = regular && (proto != NULL);
+                if (t->regular) t->proto = *proto;
+        }
         memcpy(host + o_stacks, stacks, (size_t)n_stacks * sizeof(*stacks));
         memcpy(host + o_tiles, tiles, (size_t)n_tiles * sizeof(*tiles));
         int m = 0;
@@ -351,6 +381,8 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
                 s->view.metas = (const struct tamd_meta *)(d + o_metas);
                 s->view.layer_first = (const int *)(d + o_first);
                 s->view.tiles = (const int *)(d + o_tiles);
+                s->view.slot_nodes = (const uint16_t * const *)(d + o_nodes);
+                s->view.fast_ok = fast_ok;
                 s->view.n_layers = s->n_layers;
                 s->view.geoid = geoid;
                 s->view.mode = TAMD_MODE_GENERIC;
