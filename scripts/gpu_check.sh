@@ -12,4 +12,4 @@ for mode in fast strict; do
   done
 done
 timeout -k 10 600 python bench.py --workload c3 --steps 2 --warmup 1 --no-cpu 2>/dev/null | python -c "$show" c3-fast
-TURTLE_AMD_MATH=strict timeout -k 10 600 python bench.py --workload c3 --steps 2 --warmup 1 --no-cpu 2>/dev/null | python -c "$show" c3-strict
+

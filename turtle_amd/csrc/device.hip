@@ -761,7 +761,7 @@ __global__ void k_position(tamd_view v, long n, const double * __restrict__ lat,
  * loop diverges (only lanes that crossed a boundary run it); that is accepted
  * here because this kernel serves single-step callers.  The trace kernel
  * below is the one that keeps every lane busy. */
-template <int MODE>
+template <int MODE, bool FAST>
 __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
     double * __restrict__ pos, const double * __restrict__ dir,
     double * __restrict__ lat, double * __restrict__ lon, double * __restrict__ alt,
@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                         s.m = index[2 * r], s.k = index[2 * r + 1];
                         if (s.m < 0) s.e0 = s.e1 = 0.;
                 } else
-                        d_sample<MODE>(v, ctx, px, py, pz, s);
+                        d_sample<MODE, FAST>(v, ctx, px, py, pz, s);
 
                 double ds = 0.;
                 if (s.m >= 0) {
@@ -792,13 +792,13 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                                              dz = dir[3 * r + 2];
                                 px += dx * ds, py += dy * ds, pz += dz * ds;
                                 const int medium0 = s.m;
-                                d_sample<MODE>(v, ctx, px, py, pz, s);
+                                d_sample<MODE, FAST>(v, ctx, px, py, pz, s);
                                 if (s.m != medium0) { /* [ref stepper.c:832-864] */
                                         double ds0 = -ds, ds1 = 0.;
                                         while (ds1 - ds0 > 1E-08) {
                                                 const double ds2 = 0.5 * (ds0 + ds1);
                                                 Sample s2;
-                                                d_sample<MODE>(v, ctx, px + dx * ds2,
+                                                d_sample<MODE, FAST>(v, ctx, px + dx * ds2,
                                                     py + dy * ds2, pz + dz * ds2, s2);
                                                 if (s2.m == medium0)
                                                         ds0 = ds2;
@@ -864,11 +864,23 @@ __device__ __forceinline__ ull wave_sum(ull v)
  *
  * Results do not depend on which lane runs a ray (rays are independent), so
  * the output is deterministic. */
-template <int MODE, bool FAST>
+/* FULL adds what turtle_stepper_step_n needs on top of a trace: the geodetic
+ * coordinates and bounding elevations of the final sample as outputs, and the
+ * option to start from the sample a previous call returned (the reference's
+ * `last` cache) instead of re-sampling the start point.  A batch of single
+ * steps is then just a trace with max_steps = 1, and rays that cross a
+ * boundary run their bisection while other lanes take other rays' steps. */
+struct FullIO {
+        double * lat, * lon, * alt, * elev;
+};
+
+enum { TRACE_CARRY_MEDIUM = 1, TRACE_CARRY_SAMPLE = 2 };
+
+template <int MODE, bool FAST, bool FULL>
 __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
     double * __restrict__ pos, const double * __restrict__ dir, int max_steps,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
-    int flags, ull * __restrict__ stats, ull * __restrict__ queue)
+    int flags, FullIO io, ull * __restrict__ stats, ull * __restrict__ queue)
 {
         long pool_next = 0, pool_end = 0; /* wave-uniform */
         bool exhausted = false;            /* wave-uniform */
@@ -883,6 +895,9 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         double ds = 0, ds0 = 0, ds1 = 0;
         int m = -1, k = -1, bm = -1, bk = -1;
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_capped = 0;
+        /* FULL only: the sample to publish (L) and the bisection's candidate (C):
+         * lat, lon, alt, e0, e1 */
+        double L0 = 0, L1 = 0, L2 = 0, L3 = 0, L4 = 0, C0 = 0, C1 = 0, C2 = 0, C3 = 0, C4 = 0;
 
         for (;;) {
                 /* ---- refill idle lanes from the queue ---- */
@@ -916,6 +931,17 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
                                 dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
                                 len = 0., count = 0, state = ST_INIT;
+                                if (FULL && (flags & TRACE_CARRY_SAMPLE) &&
+                                    (index[2 * ray] >= 0) && (max_steps > 0)) {
+                                        /* [ref stepper.c:708-710, :745-748] */
+                                        m = index[2 * ray], k = index[2 * ray + 1];
+                                        L0 = io.lat ? io.lat[ray] : 0.;
+                                        L1 = io.lon ? io.lon[ray] : 0.;
+                                        L2 = io.alt[ray];
+                                        L3 = io.elev[2 * ray], L4 = io.elev[2 * ray + 1];
+                                        ds = d_step_length(v, L2, L3, L4, m);
+                                        state = ST_STEP;
+                                }
                         }
                         pool_next += min((long)__popcll(mask), avail);
                 }
@@ -943,6 +969,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 else {
                                         ds1 = t;
                                         bm = s.m, bk = s.k;
+                                        if (FULL) C0 = s.lat, C1 = s.lon, C2 = s.alt, C3 = s.e0, C4 = s.e1;
                                 }
                                 located = !(ds1 - ds0 > 1E-08);
                         } else if (state == ST_STEP) {
@@ -950,6 +977,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 if (s.m == m) { /* no boundary: the step stands */
                                         len += ds;
                                         k = s.k;
+                                        if (FULL) L0 = s.lat, L1 = s.lon, L2 = s.alt, L3 = s.e0, L4 = s.e1;
                                         ds = d_step_length(v, s.alt, s.e0, s.e1, s.m);
                                         if (++count >= max_steps) {
                                                 done = true;
@@ -958,12 +986,14 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 } else { /* [ref stepper.c:832-838] */
                                         ds0 = -ds, ds1 = 0.;
                                         bm = s.m, bk = s.k;
+                                        if (FULL) C0 = s.lat, C1 = s.lon, C2 = s.alt, C3 = s.e0, C4 = s.e1;
                                         state = ST_BISECT;
                                         located = !(ds1 - ds0 > 1E-08);
                                 }
                         } else {
                                 m = s.m, k = s.k;
-                                if ((flags & TURTLE_AMD_TRACE_RESUME) && (m >= 0)) {
+                                if (FULL) L0 = s.lat, L1 = s.lon, L2 = s.alt, L3 = s.e0, L4 = s.e1;
+                                if ((flags & TRACE_CARRY_MEDIUM) && (m >= 0)) {
                                         /* the caller knows which medium the ray
                                          * is in; the sample only sizes the step */
                                         const int given = index[2 * ray];
@@ -978,13 +1008,24 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 len += ds + ds1;
                                 count++;
                                 m = bm, k = bk;
+                                if (FULL) L0 = C0, L1 = C1, L2 = C2, L3 = C3, L4 = C4;
                                 done = true;
                         }
                         if (done) {
                                 pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
                                 index[2 * ray] = m, index[2 * ray + 1] = k;
-                                if (length) length[ray] = len;
+                                if (length) /* FULL, nothing stepped: the tentative length */
+                                        length[ray] = (FULL && (count == 0) && (m >= 0)) ? ds : len;
                                 if (n_steps) n_steps[ray] = count;
+                                if (FULL) { /* sample_publish [ref stepper.c:758-778] */
+                                        if (io.lat) io.lat[ray] = L0;
+                                        if (io.lon) io.lon[ray] = L1;
+                                        if (io.alt) io.alt[ray] = L2;
+                                        if (io.elev) {
+                                                io.elev[2 * ray] = (m >= 0) ? L3 : 0.;
+                                                io.elev[2 * ray + 1] = (m >= 0) ? L4 : 0.;
+                                        }
+                                }
                                 my_rays++;
                                 my_steps += (ull)count;
                                 ray = -1;
@@ -1300,8 +1341,14 @@ extern "C" int tamd_k_step(struct tamd_view view, long n, double * pos,
         if (n <= 0) return 0;
         const dim3 grid(grid_for(n, 256)), block(256);
 #define STEP_CASE(MODE)                                                        \
-        hipLaunchKernelGGL(k_step<MODE>, grid, block, 0, g_stream, view, n, pos, dir,  \
-            lat, lon, alt, elev, step, index, flags)
+        do {                                                                   \
+                if (g_math_strict || !view.fast_ok)                            \
+                        hipLaunchKernelGGL((k_step<MODE, false>), grid, block, 0, g_stream,    \
+                            view, n, pos, dir, lat, lon, alt, elev, step, index, flags);       \
+                else                                                           \
+                        hipLaunchKernelGGL((k_step<MODE, true>), grid, block, 0, g_stream,     \
+                            view, n, pos, dir, lat, lon, alt, elev, step, index, flags);       \
+        } while (0)
         if (view.mode == TAMD_MODE_ONE_MAP)
                 STEP_CASE(TAMD_MODE_ONE_MAP);
         else if (view.mode == TAMD_MODE_ONE_STACK)
@@ -1335,40 +1382,61 @@ static int trace_blocks_per_cu(const void * kernel)
 extern "C" void tamd_dev_math_set(int strict) { g_math_strict = strict ? 1 : 0; }
 extern "C" int tamd_dev_math_get(void) { return g_math_strict; }
 
-template <int MODE, bool FAST>
+template <int MODE, bool FAST, bool FULL>
 static int launch_trace(struct tamd_view view, long n, double * pos, const double * dir,
-    int max_steps, int * index, double * length, int * n_steps, int flags, ull * stats,
-    ull * queue)
+    int max_steps, int * index, double * length, int * n_steps, int flags, FullIO io,
+    ull * stats, ull * queue)
 {
-        const void * kernel = (const void *)k_trace<MODE, FAST>;
+        const void * kernel = (const void *)k_trace<MODE, FAST, FULL>;
         long blocks = (long)g_cus * trace_blocks_per_cu(kernel);
         const long useful = (n + 255) / 256;
         if (blocks > useful) blocks = useful;
-        hipLaunchKernelGGL((k_trace<MODE, FAST>), dim3((unsigned)blocks), dim3(256), 0,
-            g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, stats,
+        hipLaunchKernelGGL((k_trace<MODE, FAST, FULL>), dim3((unsigned)blocks), dim3(256), 0,
+            g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, io, stats,
             queue);
         LAUNCH_CHECK("k_trace");
         return 0;
 }
 
-extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
-    const double * dir, int max_steps, int * index, double * length, int * n_steps,
-    int flags, unsigned long long * stats, unsigned long long * queue)
+template <bool FULL>
+static int dispatch_trace(struct tamd_view view, long n, double * pos, const double * dir,
+    int max_steps, int * index, double * length, int * n_steps, int flags, FullIO io,
+    ull * stats, ull * queue)
 {
         if (tamd_dev_init()) return 1;
         HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
         HIP_TRY(hipMemsetAsync(queue, 0, sizeof(ull), g_stream));
         if (n <= 0) return 0;
 #define TRACE_CASE(MODE)                                                       \
-        ((g_math_strict || !view.fast_ok) ?                                                       \
-                launch_trace<MODE, false>(view, n, pos, dir, max_steps, index, length, \
-                    n_steps, flags, stats, queue) :                            \
-                launch_trace<MODE, true>(view, n, pos, dir, max_steps, index, length,  \
-                    n_steps, flags, stats, queue))
+        ((g_math_strict || !view.fast_ok) ?                                    \
+                launch_trace<MODE, false, FULL>(view, n, pos, dir, max_steps, index,   \
+                    length, n_steps, flags, io, stats, queue) :                \
+                launch_trace<MODE, true, FULL>(view, n, pos, dir, max_steps, index,    \
+                    length, n_steps, flags, io, stats, queue))
         if (view.mode == TAMD_MODE_ONE_MAP) return TRACE_CASE(TAMD_MODE_ONE_MAP);
         if (view.mode == TAMD_MODE_ONE_STACK) return TRACE_CASE(TAMD_MODE_ONE_STACK);
         return TRACE_CASE(TAMD_MODE_GENERIC);
 #undef TRACE_CASE
+}
+
+extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
+    const double * dir, int max_steps, int * index, double * length, int * n_steps,
+    int flags, unsigned long long * stats, unsigned long long * queue)
+{
+        const FullIO none = { nullptr, nullptr, nullptr, nullptr };
+        return dispatch_trace<false>(view, n, pos, dir, max_steps, index, length, n_steps,
+            (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0, none, stats, queue);
+}
+
+/* n single steps with a direction: a FULL trace with max_steps = 1 */
+extern "C" int tamd_k_step_dir(struct tamd_view view, long n, double * pos,
+    const double * dir, double * lat, double * lon, double * alt, double * elev,
+    double * step, int * index, int flags, unsigned long long * stats,
+    unsigned long long * queue)
+{
+        const FullIO io = { lat, lon, alt, elev };
+        return dispatch_trace<true>(view, n, pos, dir, 1, index, step, nullptr,
+            (flags & TURTLE_AMD_STEP_RESUME) ? TRACE_CARRY_SAMPLE : 0, io, stats, queue);
 }
 
 extern "C" int tamd_k_tally(long n, const int * index, const double * length,

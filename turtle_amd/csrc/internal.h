@@ -143,6 +143,12 @@ int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length,
     int * n_steps, int flags, unsigned long long * stats,
     unsigned long long * queue);
+/* n single steps with a direction, through the trace kernel (no lane idles
+ * while another bisects); `flags` are enum turtle_amd_step_flags */
+int tamd_k_step_dir(struct tamd_view view, long n, double * pos,
+    const double * dir, double * lat, double * lon, double * alt,
+    double * elev, double * step, int * index, int flags,
+    unsigned long long * stats, unsigned long long * queue);
 int tamd_k_tally(long n, const int * index, const double * length,
     int n_media, unsigned long long * hits, int n_bins, double length_max,
     unsigned long long * histogram);

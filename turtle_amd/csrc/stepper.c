@@ -466,7 +466,14 @@ static enum turtle_return step_n(struct tamd_error * error, struct turtle_steppe
                 bad |= tamd_stage_out(&st, index, 2 * n * sizeof(int), &dix);
         }
         bad |= tamd_stage_out(&st, step, nb, &dst);
-        if (bad || tamd_k_step(stepper->view, n, dp, dd, dla, dlo, dal, del, dst, dix, flags) ||
+        /* with a direction the steps run through the trace kernel; a plain
+         * sample (direction == NULL) has no bisection and keeps the simple one */
+        if (bad ||
+            ((direction != NULL) ?
+                    tamd_k_step_dir(stepper->view, n, dp, dd, dla, dlo, dal, del, dst, dix,
+                        flags, stepper->d_stats, stepper->d_stats + 4) :
+                    tamd_k_step(stepper->view, n, dp, dd, dla, dlo, dal, del, dst, dix,
+                        flags)) ||
             ((direction != NULL) && tamd_stage_fetch(&st, position, 3 * nb, dp)) ||
             tamd_stage_fetch(&st, latitude, nb, dla) ||
             tamd_stage_fetch(&st, longitude, nb, dlo) ||
