@@ -51,6 +51,9 @@ WORKLOADS = {
     # name: (tiles (lat0, lon0, nlat, nlon), through a stack?, default rays/GPU, text)
     "c2": ((45, 3, 1, 1), False, 1_000_000,
            "C2: 1M rays/GPU, one 3601x3601 SRTMGL1 tile, trace to first boundary"),
+    "c5": ((40, 0, 10, 10), True, 10_000_000,
+           "C5: 10M scattering rays/GPU, 256 single steps each with a new isotropic "
+           "direction per step (Philox(ray, step)), 10x10 mosaic of 3601x3601 tiles"),
     "c3": ((45, 3, 4, 4), True, 10_000_000,
            "C3: 10M rays/GPU, 4x4 mosaic of 3601x3601 tiles through a stack (all "
            "tiles resident in HBM), trace to first boundary"),
@@ -102,6 +105,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--rays", type=int, default=0, help="rays per GPU (0 = the workload's)")
     ap.add_argument("--max-steps", type=int, default=100_000)
+    ap.add_argument("--scatter-steps", type=int, default=256, help="c5: steps per ray")
     ap.add_argument("--cpu-rays", type=int, default=200_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -163,9 +167,30 @@ def main():
     t_hits, t_hist, t_steps, t_size = sharding.tally_layout(n_media, n_bins)
     tally = torch.zeros(t_size, dtype=torch.int64, device=dev)
 
+    scatter = args.workload == "c5"
+    first_ray = rank * n
+    direction_k = torch.empty_like(pos0) if scatter else None
+    walk = {}
+
     def one_step():
-        pos.copy_(pos0)                      # the trace advances positions in place
-        stepper.trace_into(pos, direction, index, length, nsteps, args.max_steps)
+        if not scatter:
+            stepper.trace_into(pos, direction, index, length, nsteps, args.max_steps)
+            return
+        # C5: sample the origins once, then scatter-steps single steps, each
+        # resuming from the previous call's sample (one sample per step)
+        state = stepper.step(pos, None, outputs=False)
+        moved = torch.zeros(n, dtype=torch.int32, device=dev)
+        total = torch.zeros(n, dtype=torch.float64, device=dev)
+        for k in range(args.scatter_steps):
+            TA.isotropic(n, 0x5EED2026, k, first_ray, out=direction_k)
+            inside = state["index"][:, 0] >= 0
+            state = stepper.step(state["position"], direction_k, resume=state)
+            moved += inside.to(torch.int32)
+            total += state["step"]
+        index.copy_(state["index"])
+        length.copy_(total)
+        nsteps.copy_(moved)
+        walk["kernel_launches"] = args.scatter_steps
 
     def reduce_tally():
         tally.zero_()
@@ -174,6 +199,7 @@ def main():
         sharding.all_reduce_tally(tally, world)   # RCCL, ~8 KB: the only collective
 
     for _ in range(args.warmup):
+        pos.copy_(pos0)                      # a trace advances positions in place
         one_step()
         reduce_tally()
 
@@ -185,8 +211,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         pos.copy_(pos0)
-        ev[k][0].record()
-        stepper.trace_into(pos, direction, index, length, nsteps, args.max_steps)
+        ev[k][0].record()                    # HIP events on the launch stream
+        one_step()
         ev[k][1].record()
         reduce_tally()
     torch.cuda.synchronize()
@@ -207,7 +233,13 @@ def main():
         # algorithmic bytes of one launch: 4 x 2 B nodes per sample
         # + per ray 48 B in (pos, dir) + 44 B out (pos, index, length, n_steps)
         alg_bytes = 8.0 * stats["samples"] + 92.0 * stats["rays"]
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        launches = 1
+        if scatter:
+            # single-step mode streams the ray state every step: in 80 B (pos, dir,
+            # alt, elev[2], index[2]) + out 64 B (pos, alt, elev[2], step, index[2])
+            alg_bytes = 8.0 * stats["samples"] + 144.0 * n
+            launches = args.scatter_steps
+        achieved = alg_bytes * launches / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "ray-steps/sec (whole node) through 3601^2 SRTM tile",
             "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
@@ -217,7 +249,7 @@ def main():
             "config": {"workload": workload_text, "rays_per_gpu": n, "max_steps": args.max_steps,
                        "slope": 0.4, "resolution": 1e-2, "math": TA.get_math(),
                        "parallelism": f"rays x{world}"},
-            "kernel": {"name": TRACE_KERNEL, "ms": kernel_ms,
+            "kernel": {"name": TRACE_KERNEL, "ms": kernel_ms, "launches_per_step": launches,
                        "steps_per_launch": stats["steps"],
                        "samples_per_launch": stats["samples"],
                        "samples_per_step": stats["samples"] / max(1, stats["steps"]),

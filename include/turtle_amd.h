@@ -320,6 +320,19 @@ TURTLE_API enum turtle_return turtle_amd_tally_n(long n,
     double length_max, unsigned long long * histogram /* [n_bins + 1] */,
     int space);
 
+/* Counter-based random directions for scattering harnesses (BASELINE config
+ * C5: a new isotropic direction after every step).  Philox-4x32-10 with counter
+ * = (first_ray + r, stream) and key = seed; `stream` is typically the step
+ * number, first_ray the global index of this shard's first ray.  The same
+ * (ray, stream, seed) gives the same words on any rank.  turtle_amd_philox_n
+ * exposes the raw 4 x 32-bit blocks (for known-answer tests). */
+TURTLE_API enum turtle_return turtle_amd_isotropic_n(long n,
+    unsigned long long seed, unsigned long long stream, long first_ray,
+    double * direction /* [n][3] */, int space);
+TURTLE_API enum turtle_return turtle_amd_philox_n(long n,
+    unsigned long long seed, unsigned long long stream, long first_ray,
+    unsigned int * words /* [n][4] */, int space);
+
 #ifdef __cplusplus
 }
 #endif

@@ -505,3 +505,20 @@ def tally(index, length, n_media, n_bins, length_max, hits=None, histogram=None)
                                     _ptr(hits), n_bins, C.c_double(length_max),
                                     _ptr(histogram), sp))
     return hits, histogram
+
+
+def isotropic(n, seed, stream, first_ray=0, device=True, out=None):
+    """turtle_amd_isotropic_n: n unit vectors from Philox(ray, stream; seed)."""
+    sp = DEVICE if device else HOST
+    d = out if out is not None else _new((n, 3), sp)
+    _check(lib().turtle_amd_isotropic_n(C.c_long(n), C.c_ulonglong(seed),
+                                        C.c_ulonglong(stream), C.c_long(first_ray), _ptr(d), sp))
+    return d
+
+
+def philox(n, seed, stream, first_ray=0):
+    """Raw Philox-4x32-10 blocks [n][4] (host array), for known-answer tests."""
+    w = np.empty((n, 4), dtype=np.uint32)
+    _check(lib().turtle_amd_philox_n(C.c_long(n), C.c_ulonglong(seed), C.c_ulonglong(stream),
+                                     C.c_long(first_ray), _ptr(w), HOST))
+    return w

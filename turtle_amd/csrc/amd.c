@@ -63,3 +63,34 @@ enum turtle_return turtle_amd_tally_n(long n, const int * index, const double * 
                 return TAMD_RAISE_DEVICE();
         return TURTLE_RETURN_SUCCESS;
 }
+
+enum turtle_return turtle_amd_philox_n(long n, unsigned long long seed,
+    unsigned long long stream, long first_ray, unsigned int * words, int space)
+{
+        TAMD_ERROR_INIT(&turtle_amd_philox_n);
+        struct tamd_stage st;
+        void * dw;
+        const size_t bytes = (size_t)n * 4 * sizeof(unsigned int);
+        if (words == NULL) return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
+        if (tamd_stage_begin(&st, space, bytes) || tamd_stage_out(&st, words, bytes, &dw) ||
+            tamd_k_philox(n, seed, stream, first_ray, dw) ||
+            tamd_stage_fetch(&st, words, bytes, dw) || tamd_stage_end(&st))
+                return TAMD_RAISE_DEVICE();
+        return TURTLE_RETURN_SUCCESS;
+}
+
+enum turtle_return turtle_amd_isotropic_n(long n, unsigned long long seed,
+    unsigned long long stream, long first_ray, double * direction, int space)
+{
+        TAMD_ERROR_INIT(&turtle_amd_isotropic_n);
+        struct tamd_stage st;
+        void * dd;
+        const size_t bytes = (size_t)n * 3 * sizeof(double);
+        if (direction == NULL)
+                return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
+        if (tamd_stage_begin(&st, space, bytes) || tamd_stage_out(&st, direction, bytes, &dd) ||
+            tamd_k_isotropic(n, seed, stream, first_ray, dd) ||
+            tamd_stage_fetch(&st, direction, bytes, dd) || tamd_stage_end(&st))
+                return TAMD_RAISE_DEVICE();
+        return TURTLE_RETURN_SUCCESS;
+}

@@ -1045,6 +1045,55 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         }
 }
 
+/* ---- counter-based random directions (scattering harness, config C5) ------
+ * Philox-4x32-10 (Salmon et al., SC'11): counter = (ray id, stream), key =
+ * seed.  One block of four 32-bit words gives two 53-bit uniforms, mapped to
+ * an isotropic unit vector.  Any (ray, stream) pair can be regenerated
+ * anywhere, so shards need no shared RNG state. */
+__device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1)
+{
+        for (int round = 0; round < 10; round++) {
+                const unsigned long long p0 = 0xD2511F53ull * c[0];
+                const unsigned long long p1 = 0xCD9E8D57ull * c[2];
+                const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0;
+                const unsigned n1 = (unsigned)p1;
+                const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+                const unsigned n3 = (unsigned)p0;
+                c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+                k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+        }
+}
+
+__global__ void k_philox(long n, ull seed, ull stream, long first, unsigned * __restrict__ out)
+{
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
+             r += (long)gridDim.x * blockDim.x) {
+                const ull id = (ull)(first + r);
+                unsigned c[4] = { (unsigned)id, (unsigned)(id >> 32), (unsigned)stream,
+                        (unsigned)(stream >> 32) };
+                philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+                for (int i = 0; i < 4; i++) out[4 * r + i] = c[i];
+        }
+}
+
+__global__ void k_isotropic(long n, ull seed, ull stream, long first, double * __restrict__ dir)
+{
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
+             r += (long)gridDim.x * blockDim.x) {
+                const ull id = (ull)(first + r);
+                unsigned c[4] = { (unsigned)id, (unsigned)(id >> 32), (unsigned)stream,
+                        (unsigned)(stream >> 32) };
+                philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+                const double scale = 1. / 9007199254740992.; /* 2^-53 */
+                const double u1 = (double)(((ull)(c[0] >> 5) << 26) | (c[1] >> 6)) * scale;
+                const double u2 = (double)(((ull)(c[2] >> 5) << 26) | (c[3] >> 6)) * scale;
+                const double ct = 2. * u1 - 1.;
+                const double st = sqrt(1. - ct * ct);
+                const double phi = 2. * kPi * u2;
+                dir[3 * r] = st * cos(phi), dir[3 * r + 1] = st * sin(phi), dir[3 * r + 2] = ct;
+        }
+}
+
 /* hits[m + 1] and a linear path-length histogram, exact integer counts.
  * Per-block LDS counters (32-bit) flushed with one 64-bit atomic per bin. */
 __global__ void __launch_bounds__(256) k_tally(long n, const int * __restrict__ index,
@@ -1437,6 +1486,28 @@ extern "C" int tamd_k_step_dir(struct tamd_view view, long n, double * pos,
         const FullIO io = { lat, lon, alt, elev };
         return dispatch_trace<true>(view, n, pos, dir, 1, index, step, nullptr,
             (flags & TURTLE_AMD_STEP_RESUME) ? TRACE_CARRY_SAMPLE : 0, io, stats, queue);
+}
+
+extern "C" int tamd_k_philox(long n, unsigned long long seed, unsigned long long stream,
+    long first, unsigned * out)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        hipLaunchKernelGGL(k_philox, dim3(grid_for(n, 256)), dim3(256), 0, g_stream, n, seed,
+            stream, first, out);
+        LAUNCH_CHECK("k_philox");
+        return 0;
+}
+
+extern "C" int tamd_k_isotropic(long n, unsigned long long seed, unsigned long long stream,
+    long first, double * dir)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        hipLaunchKernelGGL(k_isotropic, dim3(grid_for(n, 256)), dim3(256), 0, g_stream, n,
+            seed, stream, first, dir);
+        LAUNCH_CHECK("k_isotropic");
+        return 0;
 }
 
 extern "C" int tamd_k_tally(long n, const int * index, const double * length,

@@ -102,6 +102,8 @@ const char * turtle_error_function(turtle_function_t * caller)
         NAME(turtle_stepper_trace_n);
         NAME(turtle_stepper_trace_stats);
         NAME(turtle_amd_tally_n);
+        NAME(turtle_amd_philox_n);
+        NAME(turtle_amd_isotropic_n);
         NAME(turtle_amd_device_set);
         NAME(turtle_amd_stream_set);
         NAME(turtle_amd_synchronize);

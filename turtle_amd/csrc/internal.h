@@ -149,6 +149,10 @@ int tamd_k_step_dir(struct tamd_view view, long n, double * pos,
     const double * dir, double * lat, double * lon, double * alt,
     double * elev, double * step, int * index, int flags,
     unsigned long long * stats, unsigned long long * queue);
+int tamd_k_philox(long n, unsigned long long seed, unsigned long long stream,
+    long first, unsigned * out);
+int tamd_k_isotropic(long n, unsigned long long seed, unsigned long long stream,
+    long first, double * dir);
 int tamd_k_tally(long n, const int * index, const double * length,
     int n_media, unsigned long long * hits, int n_bins, double length_max,
     unsigned long long * histogram);
