@@ -354,7 +354,9 @@ def test_reference_stepper_exit_and_outside(tmp_path):
     d = TA.ecef_from_horizontal([45.5], [3.5], [0.0], [0.0])[0]
     t = st.trace(p[None, :].copy(), d[None, :], max_steps=100000)
     assert t["index"][0, 0] == 1  # first it surfaces (medium 0 -> 1)
-    t = st.trace(t["position"], d[None, :], max_steps=100000)
+    # it now sits on the surface it located: carry the medium over, as the
+    # reference's cached sample does, instead of re-deriving it there
+    t = st.trace(t["position"], d[None, :], max_steps=100000, resume_index=t["index"])
     assert t["index"][0, 0] == -1 and t["n_steps"][0] < 100000
     # far away: index = {-1, -1}, elevation = {0, 0}, step 0
     far = t["position"][0] + d * 1e6

@@ -215,8 +215,53 @@ __device__ __forceinline__ double f_atan2(double y, double x)
         return copysign(a, y);
 }
 
-__device__ __forceinline__ void f_to_geodetic(
-    double x, double y, double z, double & latitude, double & longitude, double & altitude)
+/* Second-order local model of the transform around a reference point P0:
+ * with (e, n, u) the offset from P0 in its East-North-Up frame, rn = M + h0,
+ * re = N + h0 (meridional / prime-vertical radii), t = tan(lat0),
+ *   lat = lat0 + n/rn - n u/rn^2 - e^2 t/(2 re rn) - n^2 M'/(2 rn^3)
+ *   lon = lon0 + e/(re cos lat0) * (1 + (n t - u)/re)
+ *   alt = h0 + u + e^2/(2 re) + n^2/(2 rn)
+ * (the inverse, to second order, of the forward map's Taylor series).  The
+ * neglected terms are O(d^3/R^2): 2e-10 m at d = 20 m, below the 1e-9 m
+ * rounding noise of the closed form itself -- measured against it: <= 4e-9 m
+ * out to 50 m.  For comparison the reference's own local approximation
+ * (first order, finite-difference Jacobian, 1 m range, [ref stepper.c:85-171])
+ * is off by 8e-8 m.  It costs ~35 instructions instead of ~230, and that is
+ * what the long creeping rays that set a launch's run time need. */
+struct LocalModel {
+        double px, py, pz;           /* P0 (px = NaN: no model) */
+        double sl, cl, s, c;         /* sin/cos of its longitude, latitude */
+        double lat0, lon0, h0;       /* degrees, degrees, metres */
+        double inv_rn, inv_re, inv_rec, t, kee, mp;
+};
+
+constexpr double kModelRadius2 = 20. * 20.; /* m^2 */
+
+__device__ __forceinline__ bool f_model_eval(const LocalModel & M, double x, double y,
+    double z, double & latitude, double & longitude, double & altitude)
+{
+        constexpr double kRad2Deg = 57.29577951308232;
+        const double dx = x - M.px, dy = y - M.py, dz = z - M.pz;
+        const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
+        if (!(r2 < kModelRadius2)) return false; /* also when there is no model */
+        const double a = __builtin_fma(M.cl, dx, M.sl * dy);
+        const double e = __builtin_fma(M.cl, dy, -(M.sl * dx));
+        const double n = __builtin_fma(M.c, dz, -(M.s * a));
+        const double u = __builtin_fma(M.c, a, M.s * dz);
+        const double ee = e * e, nn = n * n;
+        double dphi = n * M.inv_rn;
+        dphi = dphi - dphi * u * M.inv_rn - ee * M.kee - nn * M.mp;
+        const double dlam =
+            e * M.inv_rec * __builtin_fma(__builtin_fma(n, M.t, -u), M.inv_re, 1.);
+        const double dh = u + 0.5 * __builtin_fma(ee, M.inv_re, nn * M.inv_rn);
+        latitude = __builtin_fma(dphi, kRad2Deg, M.lat0);
+        longitude = __builtin_fma(dlam, kRad2Deg, M.lon0);
+        altitude = M.h0 + dh;
+        return true;
+}
+
+__device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
+    double & latitude, double & longitude, double & altitude, LocalModel * build = nullptr)
 {
         constexpr double kRad2Deg = 57.29577951308232;
         const double a = kA;
@@ -232,6 +277,7 @@ __device__ __forceinline__ void f_to_geodetic(
                 latitude = (z >= 0.) ? 90. : -90.;
                 longitude = 0.;
                 altitude = fabs(z) - kB;
+                if (build != nullptr) build->px = __builtin_nan("");
                 return;
         }
 
@@ -275,12 +321,32 @@ __device__ __forceinline__ void f_to_geodetic(
         const double m = __builtin_fma(c, v, -(s * u));
         const double p = m * f_rcp(__builtin_fma(rf * isg, isg, f));
         (void)sg;
-        (void)iw;
 
         la += p;
         if (z < 0.) la = -la;
         latitude = la * kRad2Deg;
         altitude = __builtin_fma(0.5 * m, p, f);
+
+        if (build != nullptr) { /* everything it needs is at hand */
+                const double sf = __builtin_fma(c, p, s), cf = __builtin_fma(-s, p, c);
+                const double sphi = (z < 0.) ? -sf : sf;
+                const double isg2 = isg * isg;
+                const double M = rf * isg2; /* a (1 - e2) / g^(3/2) */
+                const double inv_rn = f_rcp(M + altitude);
+                const double inv_re = f_rcp(rg + altitude);
+                const double inv_c = f_rcp(cf);
+                const bool usable = (cf > 1e-3) && (w2 != 0.);
+                build->px = usable ? x : __builtin_nan("");
+                build->py = y, build->pz = z;
+                build->sl = y * iw, build->cl = x * iw;
+                build->s = sphi, build->c = cf;
+                build->lat0 = latitude, build->lon0 = longitude, build->h0 = altitude;
+                build->inv_rn = inv_rn, build->inv_re = inv_re;
+                build->inv_rec = inv_re * inv_c;
+                build->t = sphi * inv_c;
+                build->kee = 0.5 * build->t * inv_re * inv_rn;
+                build->mp = 1.5 * e2 * M * sphi * cf * isg2 * inv_rn * inv_rn * inv_rn;
+        }
 }
 
 /* ---- one grid --------------------------------------------------------- */
@@ -309,32 +375,38 @@ struct CellCache {
  * exact quotient decides inside/outside as in the reference); the cell index is
  * clamped instead of special-cased (hx == nx-1 gives ix = nx-2, fx = 1 either
  * way); the two nodes of a row come from one unaligned 32-bit load. */
-__device__ __forceinline__ bool f_grid_elevation(
-    const tamd_grid & g, double x, double y, double & z, CellCache * cache = nullptr)
+struct CellAt {
+        double hx, hy; /* node coordinates of the point */
+        int ix, iy;    /* its cell, clamped into the grid */
+        unsigned id;   /* iy * nx + ix */
+        bool inside;   /* [ref map.c:247-255], NaN => false */
+        bool rim;      /* within 1e-6 cell of the rim: exact quotients were used */
+};
+
+__device__ __forceinline__ CellAt f_grid_locate(const tamd_grid & g, double x, double y)
 {
-        double hx = (x - g.x0) * g.inv_dx;
-        double hy = (y - g.y0) * g.inv_dy;
+        CellAt c;
+        c.hx = (x - g.x0) * g.inv_dx;
+        c.hy = (y - g.y0) * g.inv_dy;
         const double mx = (double)(g.nx - 1), my = (double)(g.ny - 1);
-        if (__builtin_expect(
-                !((hx > 1e-6) && (hx < mx - 1e-6) && (hy > 1e-6) && (hy < my - 1e-6)), 0)) {
-                hx = (x - g.x0) / g.dx;
-                hy = (y - g.y0) / g.dy;
+        c.rim = !((c.hx > 1e-6) && (c.hx < mx - 1e-6) && (c.hy > 1e-6) && (c.hy < my - 1e-6));
+        if (__builtin_expect(c.rim, 0)) {
+                c.hx = (x - g.x0) / g.dx;
+                c.hy = (y - g.y0) / g.dy;
         }
-        /* NaN compares false: outside, as [ref map.c:233-240] */
-        const bool inside = (hx >= 0.) && (hx <= mx) && (hy >= 0.) && (hy <= my);
-        const int ix = min(max((int)hx, 0), g.nx - 2);
-        const int iy = min(max((int)hy, 0), g.ny - 2);
-        const double fx = hx - (double)ix, fy = hy - (double)iy;
-        const unsigned id = (unsigned)iy * (unsigned)g.nx + (unsigned)ix;
-        unsigned lo, hi;
-        if ((cache != nullptr) && (cache->id == id)) {
-                lo = cache->lo, hi = cache->hi;
-        } else {
-                const uint16_t * p = g.nodes + id;
-                __builtin_memcpy(&lo, p, 4);
-                __builtin_memcpy(&hi, p + g.nx, 4);
-                if (cache != nullptr) cache->id = id, cache->lo = lo, cache->hi = hi;
-        }
+        c.inside = (c.hx >= 0.) && (c.hx <= mx) && (c.hy >= 0.) && (c.hy <= my);
+        c.ix = min(max((int)c.hx, 0), g.nx - 2);
+        c.iy = min(max((int)c.hy, 0), g.ny - 2);
+        c.id = (unsigned)c.iy * (unsigned)g.nx + (unsigned)c.ix;
+        return c;
+}
+
+/* the bilinear blend of a cell's four raw nodes (lo = z00 | z10 << 16, hi =
+ * z01 | z11 << 16); one function so that every caller rounds identically */
+__device__ __forceinline__ double f_grid_blend(
+    const tamd_grid & g, const CellAt & c, unsigned lo, unsigned hi)
+{
+        const double fx = c.hx - (double)c.ix, fy = c.hy - (double)c.iy;
         double z00, z10, z01, z11;
         if (g.is_signed) {
                 z00 = (double)(int16_t)(lo & 0xffffu), z10 = (double)((int)lo >> 16);
@@ -346,8 +418,24 @@ __device__ __forceinline__ bool f_grid_elevation(
         z00 = __builtin_fma(z00, g.dz, g.z0), z10 = __builtin_fma(z10, g.dz, g.z0);
         z01 = __builtin_fma(z01, g.dz, g.z0), z11 = __builtin_fma(z11, g.dz, g.z0);
         const double gx = 1. - fx, gy = 1. - fy;
-        z = z00 * gx * gy + z01 * gx * fy + z10 * fx * gy + z11 * fx * fy;
-        return inside;
+        return z00 * gx * gy + z01 * gx * fy + z10 * fx * gy + z11 * fx * fy;
+}
+
+__device__ __forceinline__ bool f_grid_elevation(
+    const tamd_grid & g, double x, double y, double & z, CellCache * cache = nullptr)
+{
+        const CellAt c = f_grid_locate(g, x, y);
+        unsigned lo, hi;
+        if ((cache != nullptr) && (cache->id == c.id)) {
+                lo = cache->lo, hi = cache->hi;
+        } else {
+                const uint16_t * p = g.nodes + c.id;
+                __builtin_memcpy(&lo, p, 4);
+                __builtin_memcpy(&hi, p + g.nx, 4);
+                if (cache != nullptr) cache->id = c.id, cache->lo = lo, cache->hi = hi;
+        }
+        z = f_grid_blend(g, c, lo, hi);
+        return c.inside;
 }
 
 /* [ref map.c:229-277]: inclusive upper edge, truncation toward zero, the
@@ -544,9 +632,15 @@ __device__ __forceinline__ void d_load_ctx(const tamd_view & v, OneCtx & c)
 
 template <int MODE, bool FAST = false>
 __device__ __forceinline__ void d_sample(const tamd_view & v, const OneCtx & ctx, double x,
-    double y, double z, Sample & s, CellCache * cache = nullptr)
+    double y, double z, Sample & s, CellCache * cache = nullptr,
+    LocalModel * model = nullptr)
 {
-        if (FAST)
+        if (FAST && (model != nullptr)) {
+                /* inside the model's ball: ~35 instructions; else the closed
+                 * form, which re-centres the model on this point */
+                if (!f_model_eval(*model, x, y, z, s.lat, s.lon, s.alt))
+                        f_to_geodetic(x, y, z, s.lat, s.lon, s.alt, model);
+        } else if (FAST)
                 f_to_geodetic(x, y, z, s.lat, s.lon, s.alt);
         else
                 d_to_geodetic(x, y, z, s.lat, s.lon, s.alt);
@@ -829,6 +923,7 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
 /* ---- the hot kernel ---------------------------------------------------- */
 
 constexpr int kChunk = 64; /* rays a wave draws from the global queue at once */
+constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many live lanes */
 
 enum { ST_INIT = 0, ST_STEP = 1, ST_BISECT = 2 };
 
@@ -876,12 +971,32 @@ struct FullIO {
 
 enum { TRACE_CARRY_MEDIUM = 1, TRACE_CARRY_SAMPLE = 2 };
 
-template <int MODE, bool FAST, bool FULL>
+/* Two-phase launches.  Steps per ray are heavy-tailed (C2: median 163, max
+ * 11 327) and a ray's samples are sequential, so a launch lasts as long as its
+ * longest ray.  Phase A therefore PARKS any ray that reaches `park_after` steps
+ * (its state goes back to the ray arrays, its id to a list) and phase B resumes
+ * the parked rays, packed into few waves that run alone on their SIMDs, with
+ * the local model (MODEL) that makes a creeping ray's sample ~7x cheaper.
+ * Which arithmetic a sample uses depends only on the ray's own step count and
+ * positions, never on scheduling: results stay deterministic. */
+struct PhaseIO {
+        const int * ids;     /* phase B: the parked ray ids (else NULL: slot == ray) */
+        const ull * n_dev;   /* phase B: their number, on the device */
+        int * parked;        /* phase A: where to list parked rays (or NULL) */
+        ull * n_parked;
+        int park_after;      /* phase A: park at this step count (<= 0: never) */
+        int accumulate;      /* phase B: length / n_steps continue from the arrays */
+};
+
+template <int MODE, bool FAST, bool FULL, bool MODEL>
 __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
     double * __restrict__ pos, const double * __restrict__ dir, int max_steps,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
-    int flags, FullIO io, ull * __restrict__ stats, ull * __restrict__ queue)
+    int flags, FullIO io, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
 {
+        if (ph.n_dev != nullptr) n = (long)*ph.n_dev;
+        LocalModel model;
+        model.px = __builtin_nan("");
         long pool_next = 0, pool_end = 0; /* wave-uniform */
         bool exhausted = false;            /* wave-uniform */
         OneCtx ctx;
@@ -890,10 +1005,10 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
 
         long ray = -1;
         bool dead = false;
-        int state = ST_INIT, count = 0;
+        int state = ST_INIT, count = 0, count0 = 0;
         double bx = 0, by = 0, bz = 0, dx = 0, dy = 0, dz = 0, len = 0;
         double ds = 0, ds0 = 0, ds1 = 0;
-        int m = -1, k = -1, bm = -1, bk = -1;
+        int m = -1, k = -1, bm = -1, bk = -1, halvings = 0;
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_capped = 0;
         /* FULL only: the sample to publish (L) and the bisection's candidate (C):
          * lat, lon, alt, e0, e1 */
@@ -928,9 +1043,13 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                         if (need && (rank < avail)) {
                                 ray = pool_next + rank;
+                                if (ph.ids != nullptr) ray = ph.ids[ray];
+                                if (MODEL) model.px = __builtin_nan("");
                                 bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
                                 dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
                                 len = 0., count = 0, state = ST_INIT;
+                                if (ph.accumulate) len = length[ray], count = n_steps[ray];
+                                count0 = count;
                                 if (FULL && (flags & TRACE_CARRY_SAMPLE) &&
                                     (index[2 * ray] >= 0) && (max_steps > 0)) {
                                         /* [ref stepper.c:708-710, :745-748] */
@@ -947,6 +1066,48 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                 }
                 if (__ballot(ray >= 0) == 0) break;
 
+                /* ---- creep loop (phase B, sparse waves) ---------------------------
+                 * What is left at the end of a launch is a handful of rays
+                 * skimming the ground with ~0.5 m steps for thousands of steps.
+                 * While every live lane of the wave is such a ray -- stepping,
+                 * inside its local model's ball and inside its cached cell --
+                 * a step needs no transform, no load and no state machine: this
+                 * loop does just that, and hands any lane that needs more (new
+                 * cell, re-centring, a boundary, the step cap) back to the
+                 * general iteration below WITHOUT having committed that step.
+                 * It calls the same functions on the same values as the general
+                 * path, so results do not depend on whether it engaged. */
+                if (MODEL && (MODE == TAMD_MODE_ONE_MAP) &&
+                    (__popcll(__ballot(ray >= 0)) <= kCreepLanes)) {
+                        for (int it = 0; it < 4096; it++) {
+                                bool fail = false;
+                                double qx = 0, qy = 0, qz = 0, alt = 0, elevation = 0;
+                                if (ray >= 0) {
+                                        double lat, lon;
+                                        qx = bx + dx * ds, qy = by + dy * ds, qz = bz + dz * ds;
+                                        fail = (state != ST_STEP) || (count + 1 >= max_steps) ||
+                                            !f_model_eval(model, qx, qy, qz, lat, lon, alt);
+                                        const CellAt c = f_grid_locate(ctx.grid, lon, lat);
+                                        fail = fail || c.rim || !c.inside || (c.id != cell.id);
+                                        elevation = f_grid_blend(ctx.grid, c, cell.lo, cell.hi) +
+                                            ctx.offset;
+                                        const int mm = (elevation >= alt) ? 0 : 1;
+                                        fail = fail || (mm != m);
+                                }
+                                if (__ballot(fail) != 0) break;
+                                if (ray >= 0) {
+                                        bx = qx, by = qy, bz = qz;
+                                        len += ds;
+                                        count++;
+                                        my_samples++;
+                                        const Sample t = { 0., 0., alt, (m == 1) ? elevation : -DBL_MAX,
+                                                (m == 0) ? elevation : DBL_MAX, m, 0 };
+                                        ds = d_step_length(v, t.alt, t.e0, t.e1, t.m);
+                                }
+                        }
+                }
+
+                bool park = false;
                 if (ray >= 0) {
                         /* ---- one sample at q = B + d * t ---- */
                         double t = 0.;
@@ -958,7 +1119,8 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
 
                         Sample s;
                         d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
-                            (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr);
+                            (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr,
+                            MODEL ? &model : nullptr);
                         my_samples++;
 
                         /* ---- bookkeeping (cheap, may diverge) ---- */
@@ -971,7 +1133,10 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         bm = s.m, bk = s.k;
                                         if (FULL) C0 = s.lat, C1 = s.lon, C2 = s.alt, C3 = s.e0, C4 = s.e1;
                                 }
-                                located = !(ds1 - ds0 > 1E-08);
+                                /* a bracket of finite doubles is below 1e-8 after at
+                                 * most ~1100 halvings; the cap only guards against
+                                 * non-finite input (a kernel must always end) */
+                                located = !(ds1 - ds0 > 1E-08) || (++halvings > 1200);
                         } else if (state == ST_STEP) {
                                 bx = qx, by = qy, bz = qz;
                                 if (s.m == m) { /* no boundary: the step stands */
@@ -982,26 +1147,36 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         if (++count >= max_steps) {
                                                 done = true;
                                                 my_capped++;
-                                        }
+                                        } else if ((ph.park_after > 0) && (count >= ph.park_after))
+                                                park = true;
                                 } else { /* [ref stepper.c:832-838] */
                                         ds0 = -ds, ds1 = 0.;
                                         bm = s.m, bk = s.k;
                                         if (FULL) C0 = s.lat, C1 = s.lon, C2 = s.alt, C3 = s.e0, C4 = s.e1;
-                                        state = ST_BISECT;
+                                        state = ST_BISECT, halvings = 0;
                                         located = !(ds1 - ds0 > 1E-08);
                                 }
                         } else {
                                 m = s.m, k = s.k;
                                 if (FULL) L0 = s.lat, L1 = s.lon, L2 = s.alt, L3 = s.e0, L4 = s.e1;
-                                if ((flags & TRACE_CARRY_MEDIUM) && (m >= 0)) {
-                                        /* the caller knows which medium the ray
-                                         * is in; the sample only sizes the step */
-                                        const int given = index[2 * ray];
-                                        if ((given >= 0) && (given <= v.n_layers)) m = given;
-                                }
                                 ds = (m >= 0) ? d_step_length(v, s.alt, s.e0, s.e1, m) : 0.;
+                                if ((flags & TRACE_CARRY_MEDIUM) && (m >= 0)) {
+                                        /* The caller knows which medium the ray
+                                         * is in; the sample only sizes the step.
+                                         * If the two disagree the ray sits ON the
+                                         * boundary between them (the bisection
+                                         * left it within 1e-8 m): the distance to
+                                         * the nearest surface is ~0 and the
+                                         * reference's cached sample would give the
+                                         * minimum step [ref stepper.c:812-813]. */
+                                        const int given = index[2 * ray];
+                                        if ((given >= 0) && (given <= v.n_layers) && (given != m)) {
+                                                m = given;
+                                                ds = v.resolution;
+                                        }
+                                }
                                 state = ST_STEP;
-                                done = (m < 0) || (max_steps <= 0);
+                                done = (m < 0) || (count >= max_steps);
                         }
                         if (located) { /* [ref stepper.c:861-863] */
                                 bx = bx + dx * ds1, by = by + dy * ds1, bz = bz + dz * ds1;
@@ -1027,7 +1202,27 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         }
                                 }
                                 my_rays++;
-                                my_steps += (ull)count;
+                                my_steps += (ull)(count - count0);
+                                ray = -1;
+                        }
+                }
+                /* ---- park over-long rays (phase A; whole wave takes part) ---- */
+                const ull pmask = __ballot(park);
+                if (pmask != 0) {
+                        const int leader = __builtin_ctzll(pmask);
+                        ull base = 0;
+                        if ((int)(threadIdx.x & 63) == leader)
+                                base = atomicAdd(ph.n_parked, (ull)__popcll(pmask));
+                        base = __shfl(base, leader, 64);
+                        if (park) {
+                                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pmask >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((unsigned)pmask, 0));
+                                ph.parked[base + rank] = (int)ray;
+                                pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
+                                index[2 * ray] = m, index[2 * ray + 1] = k;
+                                length[ray] = len;
+                                n_steps[ray] = count;
+                                my_steps += (ull)(count - count0);
                                 ray = -1;
                         }
                 }
@@ -1431,50 +1626,93 @@ static int trace_blocks_per_cu(const void * kernel)
 extern "C" void tamd_dev_math_set(int strict) { g_math_strict = strict ? 1 : 0; }
 extern "C" int tamd_dev_math_get(void) { return g_math_strict; }
 
-template <int MODE, bool FAST, bool FULL>
-static int launch_trace(struct tamd_view view, long n, double * pos, const double * dir,
-    int max_steps, int * index, double * length, int * n_steps, int flags, FullIO io,
-    ull * stats, ull * queue)
+template <int MODE, bool FAST, bool FULL, bool MODEL>
+static int launch_trace(struct tamd_view view, long n, bool n_on_device, double * pos,
+    const double * dir, int max_steps, int * index, double * length, int * n_steps,
+    int flags, FullIO io, PhaseIO ph, ull * stats, ull * queue)
 {
-        const void * kernel = (const void *)k_trace<MODE, FAST, FULL>;
+        const void * kernel = (const void *)k_trace<MODE, FAST, FULL, MODEL>;
         long blocks = (long)g_cus * trace_blocks_per_cu(kernel);
         const long useful = (n + 255) / 256;
-        if (blocks > useful) blocks = useful;
-        hipLaunchKernelGGL((k_trace<MODE, FAST, FULL>), dim3((unsigned)blocks), dim3(256), 0,
-            g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, io, stats,
-            queue);
+        if (!n_on_device && (blocks > useful)) blocks = useful;
+        if (n_on_device) {
+                /* the parked rays are a few percent of n, and long: spread them
+                 * thin (down to one wave per SIMD) so that each advances fast */
+                long wide = useful / 8;
+                if (wide < (long)g_cus) wide = (long)g_cus;
+                if (blocks > wide) blocks = wide;
+        }
+        hipLaunchKernelGGL((k_trace<MODE, FAST, FULL, MODEL>), dim3((unsigned)blocks),
+            dim3(256), 0, g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags,
+            io, ph, stats, queue);
         LAUNCH_CHECK("k_trace");
         return 0;
+}
+
+/* Step count at which phase A parks a ray (fast math only; 0 disables the
+ * second phase).  TURTLE_AMD_PARK overrides it for experiments. */
+static int park_threshold(void)
+{
+        static int value = -1;
+        if (value < 0) {
+                const char * env = getenv("TURTLE_AMD_PARK");
+                value = ((env != nullptr) && (*env != 0)) ? atoi(env) : 512;
+                if (value < 0) value = 0;
+        }
+        return value;
+}
+
+template <int MODE, bool FULL>
+static int run_trace(struct tamd_view view, long n, double * pos, const double * dir,
+    int max_steps, int * index, double * length, int * n_steps, int flags, FullIO io,
+    int * parked, ull * stats, ull * queue)
+{
+        const PhaseIO one = { nullptr, nullptr, nullptr, nullptr, 0, 0 };
+        if (g_math_strict || !view.fast_ok)
+                return launch_trace<MODE, false, FULL, false>(view, n, false, pos, dir,
+                    max_steps, index, length, n_steps, flags, io, one, stats, queue);
+        const int park = park_threshold();
+        if (FULL || (parked == nullptr) || (park <= 0) || (max_steps <= park) ||
+            (length == nullptr) || (n_steps == nullptr))
+                return launch_trace<MODE, true, FULL, false>(view, n, false, pos, dir,
+                    max_steps, index, length, n_steps, flags, io, one, stats, queue);
+        const PhaseIO a = { nullptr, nullptr, parked, queue + 2, park, 0 };
+        if (launch_trace<MODE, true, FULL, false>(view, n, false, pos, dir, max_steps, index,
+                length, n_steps, flags, io, a, stats, queue))
+                return 1;
+        const PhaseIO b = { parked, queue + 2, nullptr, nullptr, 0, 1 };
+        return launch_trace<MODE, true, FULL, true>(view, n, true, pos, dir, max_steps, index,
+            length, n_steps, flags | TRACE_CARRY_MEDIUM, io, b, stats, queue + 1);
 }
 
 template <bool FULL>
 static int dispatch_trace(struct tamd_view view, long n, double * pos, const double * dir,
     int max_steps, int * index, double * length, int * n_steps, int flags, FullIO io,
-    ull * stats, ull * queue)
+    int * parked, ull * stats, ull * queue)
 {
         if (tamd_dev_init()) return 1;
         HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
-        HIP_TRY(hipMemsetAsync(queue, 0, sizeof(ull), g_stream));
+        HIP_TRY(hipMemsetAsync(queue, 0, 3 * sizeof(ull), g_stream));
         if (n <= 0) return 0;
-#define TRACE_CASE(MODE)                                                       \
-        ((g_math_strict || !view.fast_ok) ?                                    \
-                launch_trace<MODE, false, FULL>(view, n, pos, dir, max_steps, index,   \
-                    length, n_steps, flags, io, stats, queue) :                \
-                launch_trace<MODE, true, FULL>(view, n, pos, dir, max_steps, index,    \
-                    length, n_steps, flags, io, stats, queue))
-        if (view.mode == TAMD_MODE_ONE_MAP) return TRACE_CASE(TAMD_MODE_ONE_MAP);
-        if (view.mode == TAMD_MODE_ONE_STACK) return TRACE_CASE(TAMD_MODE_ONE_STACK);
-        return TRACE_CASE(TAMD_MODE_GENERIC);
-#undef TRACE_CASE
+        if (view.mode == TAMD_MODE_ONE_MAP)
+                return run_trace<TAMD_MODE_ONE_MAP, FULL>(view, n, pos, dir, max_steps, index,
+                    length, n_steps, flags, io, parked, stats, queue);
+        if (view.mode == TAMD_MODE_ONE_STACK)
+                return run_trace<TAMD_MODE_ONE_STACK, FULL>(view, n, pos, dir, max_steps, index,
+                    length, n_steps, flags, io, parked, stats, queue);
+        return run_trace<TAMD_MODE_GENERIC, FULL>(view, n, pos, dir, max_steps, index, length,
+            n_steps, flags, io, parked, stats, queue);
 }
 
+/* queue[0], queue[1]: work counters of the two phases; queue[2]: parked rays */
 extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
-    int flags, unsigned long long * stats, unsigned long long * queue)
+    int flags, int * parked, unsigned long long * stats, unsigned long long * queue)
 {
         const FullIO none = { nullptr, nullptr, nullptr, nullptr };
         return dispatch_trace<false>(view, n, pos, dir, max_steps, index, length, n_steps,
-            (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0, none, stats, queue);
+            (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0, none, parked, stats,
+            queue);
 }
 
 /* n single steps with a direction: a FULL trace with max_steps = 1 */
@@ -1485,7 +1723,8 @@ extern "C" int tamd_k_step_dir(struct tamd_view view, long n, double * pos,
 {
         const FullIO io = { lat, lon, alt, elev };
         return dispatch_trace<true>(view, n, pos, dir, 1, index, step, nullptr,
-            (flags & TURTLE_AMD_STEP_RESUME) ? TRACE_CARRY_SAMPLE : 0, io, stats, queue);
+            (flags & TURTLE_AMD_STEP_RESUME) ? TRACE_CARRY_SAMPLE : 0, io, nullptr, stats,
+            queue);
 }
 
 extern "C" int tamd_k_philox(long n, unsigned long long seed, unsigned long long stream,

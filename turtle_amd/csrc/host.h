@@ -102,7 +102,9 @@ struct turtle_stepper {
         void * d_tables;
         size_t d_tables_size;
         struct tamd_view view;
-        unsigned long long * d_stats; /* 4 stats + 1 queue counter */
+        unsigned long long * d_stats; /* 4 stats + 3 queue counters (+1 spare) */
+        int * d_parked;               /* ids of rays handed to the second phase */
+        long parked_capacity;
 };
 
 /* Any change to what kernels may read (map nodes, tiles, layers) bumps this. */

@@ -137,11 +137,13 @@ int tamd_k_position(struct tamd_view view, long n, const double * lat,
 int tamd_k_step(struct tamd_view view, long n, double * pos,
     const double * dir, double * lat, double * lon, double * alt,
     double * elev, double * step, int * index, int flags);
-/* stats: 4 x uint64 on the device (rays, steps, samples, capped);
- * queue: 1 x uint64 work counter; both zeroed by the launcher. */
+/* stats: 4 x uint64 on the device (rays, steps, samples, capped); queue: 3 x
+ * uint64 (work counters of the two phases, number of parked rays); both zeroed
+ * by the launcher.  parked: int[n] scratch for the ids of rays handed to the
+ * second phase, or NULL for a single-phase launch. */
 int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length,
-    int * n_steps, int flags, unsigned long long * stats,
+    int * n_steps, int flags, int * parked, unsigned long long * stats,
     unsigned long long * queue);
 /* n single steps with a direction, through the trace kernel (no lane idles
  * while another bisects); `flags` are enum turtle_amd_step_flags */

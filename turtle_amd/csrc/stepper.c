@@ -38,9 +38,11 @@ enum turtle_return turtle_stepper_destroy(struct turtle_stepper ** stepper)
         for (i = 0; i < s->n_data; i++) /* owned clients [ref stepper.c:578-586] */
                 if (s->data[i].client != NULL) turtle_client_destroy(&s->data[i].client);
         for (i = 0; i < s->n_layers; i++) free(s->layers[i].meta);
-        if ((s->d_tables != NULL) || (s->d_stats != NULL)) tamd_dev_sync();
+        if ((s->d_tables != NULL) || (s->d_stats != NULL) || (s->d_parked != NULL))
+                tamd_dev_sync();
         tamd_dev_free(s->d_tables);
         tamd_dev_free(s->d_stats);
+        tamd_dev_free(s->d_parked);
         free(s->data);
         free(s->layers);
         free(s);
@@ -503,6 +505,17 @@ enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long 
         if ((position == NULL) || (direction == NULL) || (index == NULL))
                 return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
         FLATTEN_OR_RETURN(stepper);
+        if ((n > stepper->parked_capacity) && (n < 2147483647L)) {
+                /* scratch list for the two-phase launch (grow-only) */
+                if (stepper->d_parked != NULL) {
+                        tamd_dev_sync();
+                        tamd_dev_free(stepper->d_parked);
+                        stepper->d_parked = NULL, stepper->parked_capacity = 0;
+                }
+                if (tamd_dev_malloc((void **)&stepper->d_parked, (size_t)n * sizeof(int)))
+                        return TAMD_RAISE_DEVICE();
+                stepper->parked_capacity = n;
+        }
         struct tamd_stage st;
         void *dp, *dd, *dix, *dlen, *dns;
         const size_t nb = (size_t)n * sizeof(double);
@@ -515,7 +528,8 @@ enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long 
             tamd_stage_out(&st, length, nb, &dlen) ||
             tamd_stage_out(&st, n_steps, n * sizeof(int), &dns) ||
             tamd_k_trace(stepper->view, n, dp, dd, max_steps, dix, dlen, dns, flags,
-                stepper->d_stats, stepper->d_stats + 4) ||
+                (n <= stepper->parked_capacity) ? stepper->d_parked : NULL, stepper->d_stats,
+                stepper->d_stats + 4) ||
             tamd_stage_fetch(&st, position, 3 * nb, dp) ||
             tamd_stage_fetch(&st, index, 2 * n * sizeof(int), dix) ||
             tamd_stage_fetch(&st, length, nb, dlen) ||
