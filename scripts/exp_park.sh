@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 show='import sys,json; d=json.loads(sys.stdin.readline()); k=d["kernel"]; print(sys.argv[1], "rays",d["config"]["rays_per_gpu"],"kernel_ms",round(k["ms"],2),"Gsteps/s",round(k["gpu_steps_per_s"]/1e9,2), "samples/step", round(k["samples_per_step"],4))'
-for park in 0 256 512 1024; do
+for park in 384 512 768; do
   for r in 1000000 16000000; do
     TURTLE_AMD_PARK=$park timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu --rays $r 2>/dev/null | python -c "$show" park$park
   done
