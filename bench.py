@@ -30,7 +30,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
-TRACE_KERNEL = "k_trace"
+TRACE_KERNEL = "k_trace (phase A: all rays up to 512 steps; phase B: the parked long rays)"
+
+
+def measured_traffic(workload, rays, math):
+    """HBM-side bytes per trace_n call from the committed PMC passes
+    (profiles/*_pmc.json, written by scripts/profile_round.sh): counters cannot
+    be read from inside the timed process, so the figure is the offline
+    measurement of the same command, or None when none matches."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if (d.get("workload"), d.get("rays_per_gpu"), d.get("math")) == (workload, rays, math):
+            return d.get("traffic_bytes_per_launch"), os.path.basename(path)
+    return None, None
 
 
 def host_cores():
@@ -240,6 +256,7 @@ def main():
             alg_bytes = 8.0 * stats["samples"] + 144.0 * n
             launches = args.scatter_steps
         achieved = alg_bytes * launches / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(args.workload, n, TA.get_math())
         line = {
             "metric": "ray-steps/sec (whole node) through 3601^2 SRTM tile",
             "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
@@ -256,9 +273,13 @@ def main():
                        "gpu_steps_per_s": stats["steps"] / (kernel_ms * 1e-3),
                        "capped_rays": stats["capped"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "note": "algorithmic bytes; the kernel is fp64-VALU/latency "
-                                 "shaped, see DESIGN.md"},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes * launches,
+                         "note": "achieved = algorithmic bytes / kernel time; traffic = "
+                                 "FETCH_SIZE+WRITE_SIZE bytes per launch (PMC, offline). The "
+                                 "kernel is fp64-VALU/latency shaped, not bandwidth shaped: "
+                                 "see DESIGN.md"},
             "tally": {"hits": [int(v) for v in tally[t_hits].tolist()]},
         }
         if not args.no_cpu and world == 1:
