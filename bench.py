@@ -122,7 +122,8 @@ def main():
     ap.add_argument("--rays", type=int, default=0, help="rays per GPU (0 = the workload's)")
     ap.add_argument("--max-steps", type=int, default=100_000)
     ap.add_argument("--scatter-steps", type=int, default=256, help="c5: steps per ray")
-    ap.add_argument("--cpu-rays", type=int, default=200_000)
+    ap.add_argument("--cpu-rays", type=int, default=1_000_000,
+                    help="rays of the CPU-baseline sample (default: the whole C2 batch)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

@@ -12,13 +12,19 @@
  * GPU/CPU differences (<= 1e-9 relative on a path length; the parity bar is
  * 1e-6).  Citations [ref FILE:LINE] are paths under the reference tree.
  *
+ * The trace kernel also has a FAST arithmetic (default), a two-phase launch and
+ * a local second-order model for long rays: see the comments at f_to_geodetic,
+ * LocalModel, PhaseIO and k_trace, and DESIGN.md 3.1.
+ *
  * Kernels (one thread = one ray/point; all are fp64 VALU work with a 4-node
  * 16-bit gather per sample, see DESIGN.md for the roofline of each):
  *   k_ecef_*        batch ECEF transforms              [ref ecef.c:41-207]
  *   k_elevation     batch bilinear lookup, map/stack   [ref map.c:229-277, stack.c:300-361]
  *   k_position      batch turtle_stepper_position      [ref stepper.c:877-931]
- *   k_step          batch turtle_stepper_step          [ref stepper.c:780-875]
- *   k_trace         persistent-wave trace-to-boundary loop (the hot kernel)
+ *   k_step          batch sample-only turtle_stepper_step [ref stepper.c:780-821]
+ *   k_trace         persistent-wave trace-to-boundary loop (the hot kernel);
+ *                   single steps with a direction are traces with max_steps = 1
+ *   k_isotropic     Philox-4x32-10 isotropic directions (scattering harness)
  *   k_tally         hit counts + path-length histogram (uint64, exact)
  */
 #include <hip/hip_runtime.h>
