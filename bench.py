@@ -136,10 +136,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # one process per GPU; TURTLE_BENCH_BACKEND=gloo lets several ranks share a
+    # GPU to rehearse the N > 1 path on a one-GPU box (RCCL needs a GPU per rank)
+    backend = os.environ.get("TURTLE_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
+    os.environ["LOCAL_RANK"] = str(local)      # the C library picks its device from it
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     import turtle_amd as TA
     from turtle_amd import sharding, synth
@@ -236,7 +244,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_all = torch.tensor([elapsed], dtype=torch.float64,
+                         device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     elapsed = float(t_all.item())

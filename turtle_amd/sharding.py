@@ -35,7 +35,12 @@ def all_reduce_tally(tally, world: int):
     """Sum the tally over ranks in place (no-op for one rank)."""
     if world > 1:
         import torch.distributed as dist
-        dist.all_reduce(tally)
+        if tally.is_cuda and dist.get_backend() != "nccl":
+            host = tally.cpu()          # rehearsal over gloo: reduce on the host
+            dist.all_reduce(host)
+            tally.copy_(host)
+        else:
+            dist.all_reduce(tally)
     return tally
 
 
