@@ -250,7 +250,9 @@ __device__ __forceinline__ bool f_model_eval(const LocalModel & M, double x, dou
         constexpr double kRad2Deg = 57.29577951308232;
         const double dx = x - M.px, dy = y - M.py, dz = z - M.pz;
         const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-        if (!(r2 < radius2)) return false; /* also when there is no model */
+        /* no early exit: the few dozen operations below are cheaper than a
+         * divergent branch, and a caller ignores the outputs when told `false`
+         * (r2 is NaN when there is no model) */
         const double a = __builtin_fma(M.cl, dx, M.sl * dy);
         const double e = __builtin_fma(M.cl, dy, -(M.sl * dx));
         const double n = __builtin_fma(M.c, dz, -(M.s * a));
@@ -264,7 +266,7 @@ __device__ __forceinline__ bool f_model_eval(const LocalModel & M, double x, dou
         latitude = __builtin_fma(dphi, kRad2Deg, M.lat0);
         longitude = __builtin_fma(dlam, kRad2Deg, M.lon0);
         altitude = M.h0 + dh;
-        return true;
+        return r2 < radius2;
 }
 
 __device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
@@ -1123,30 +1125,42 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                  * and 15.7 ms without a creep loop. */
                 if (MODEL && (MODE == TAMD_MODE_ONE_MAP) &&
                     (__popcll(__ballot(ray >= 0)) <= kCreepLanes)) {
+                        const tamd_grid & g = ctx.grid;
+                        const double mx = (double)(g.nx - 1) - 1e-6, my = (double)(g.ny - 1) - 1e-6;
                         for (int it = 0; it < 4096; it++) {
-                                bool fail = false;
-                                double qx = 0, qy = 0, qz = 0, alt = 0, elevation = 0;
-                                if (ray >= 0) {
-                                        double lat, lon;
-                                        qx = bx + dx * ds, qy = by + dy * ds, qz = bz + dz * ds;
-                                        fail = (state != ST_STEP) || (count + 1 >= max_steps) ||
-                                            !f_model_eval(model, qx, qy, qz, lat, lon, alt);
-                                        const CellAt c = f_grid_locate(ctx.grid, lon, lat);
-                                        fail = fail || c.rim || !c.inside || (c.id != cell.id);
-                                        elevation = f_grid_blend(ctx.grid, c, cell.lo, cell.hi) +
-                                            ctx.offset;
-                                        const int mm = (elevation >= alt) ? 0 : 1;
-                                        fail = fail || (mm != m);
-                                }
-                                if (__ballot(fail) != 0) break;
-                                if (ray >= 0) {
+                                /* no short-circuits below: every lane computes
+                                 * everything (garbage is harmless, nothing is
+                                 * committed on failure) and the tests are OR-ed */
+                                const double qx = bx + dx * ds, qy = by + dy * ds,
+                                             qz = bz + dz * ds;
+                                double lat, lon, alt;
+                                const bool near = f_model_eval(model, qx, qy, qz, lat, lon, alt);
+                                /* f_grid_locate without its rim fallback: a point
+                                 * within 1e-6 cell of the rim leaves the loop */
+                                CellAt c;
+                                c.hx = (lon - g.x0) * g.inv_dx;
+                                c.hy = (lat - g.y0) * g.inv_dy;
+                                const bool interior =
+                                    (c.hx > 1e-6) & (c.hx < mx) & (c.hy > 1e-6) & (c.hy < my);
+                                c.ix = min(max((int)c.hx, 0), g.nx - 2);
+                                c.iy = min(max((int)c.hy, 0), g.ny - 2);
+                                c.id = (unsigned)c.iy * (unsigned)g.nx + (unsigned)c.ix;
+                                const double elevation =
+                                    f_grid_blend(g, c, cell.lo, cell.hi) + ctx.offset;
+                                const int mm = (elevation >= alt) ? 0 : 1;
+                                const bool ok = (ray >= 0) & (state == ST_STEP) &
+                                    (count + 1 < max_steps) & near & interior &
+                                    (c.id == cell.id) & (mm == m);
+                                if (__ballot((ray >= 0) & !ok) != 0) break;
+                                if (ok) {
                                         bx = qx, by = qy, bz = qz;
                                         len += ds;
                                         count++;
                                         my_samples++;
-                                        const Sample t = { 0., 0., alt, (m == 1) ? elevation : -DBL_MAX,
-                                                (m == 0) ? elevation : DBL_MAX, m, 0 };
-                                        ds = d_step_length(v, t.alt, t.e0, t.e1, t.m);
+                                        /* d_step_length for one surface: both of its
+                                         * cases are |alt - elevation| */
+                                        ds = fabs(alt - elevation) * v.slope;
+                                        if (ds < v.resolution) ds = v.resolution;
                                 }
                         }
                 }
