@@ -110,6 +110,13 @@ TURTLE_API enum turtle_return turtle_map_node(const struct turtle_map * map,
 TURTLE_API enum turtle_return turtle_map_elevation(
     const struct turtle_map * map, double x, double y, double * elevation,
     int * inside);
+/* [ref include/turtle.h:515-517; impl map.c:280-392].  gx, gy are in-out: the
+ * reference leaves them untouched outside the map and, by a slip at
+ * map.c:352-353 that is reproduced, stores the y-gradient in gx and leaves gy
+ * untouched for a point in the grid's first half-row. */
+TURTLE_API enum turtle_return turtle_map_gradient(
+    const struct turtle_map * map, double x, double y, double * gx, double * gy,
+    int * inside);
 TURTLE_API const struct turtle_projection * turtle_map_projection(
     const struct turtle_map * map);
 TURTLE_API void turtle_map_meta(const struct turtle_map * map,
@@ -129,6 +136,11 @@ TURTLE_API enum turtle_return turtle_stack_load(struct turtle_stack * stack);
 TURTLE_API enum turtle_return turtle_stack_elevation(
     struct turtle_stack * stack, double latitude, double longitude,
     double * elevation, int * inside);
+
+/* [ref include/turtle.h:748-750; impl stack.c:364-388] */
+TURTLE_API enum turtle_return turtle_stack_gradient(
+    struct turtle_stack * stack, double latitude, double longitude,
+    double * glat, double * glon, int * inside);
 
 /* ---- clients [ref include/turtle.h:773-842; impl client.c:41-188] ----
  * Same answers as the stack; the reference's per-thread tile pinning has no
@@ -251,6 +263,16 @@ TURTLE_API enum turtle_return turtle_map_elevation_n(
 TURTLE_API enum turtle_return turtle_stack_elevation_n(
     struct turtle_stack * stack, long n, const double * latitude,
     const double * longitude, double * elevation, int * inside, int space);
+
+/* n gradients (the surface normal a Monte-Carlo needs at a hit point).  The
+ * output arrays are in-out, as in the scalar calls. */
+TURTLE_API enum turtle_return turtle_map_gradient_n(
+    const struct turtle_map * map, long n, const double * x, const double * y,
+    double * gx, double * gy, int * inside, int space);
+TURTLE_API enum turtle_return turtle_stack_gradient_n(
+    struct turtle_stack * stack, long n, const double * latitude,
+    const double * longitude, double * glat, double * glon, int * inside,
+    int space);
 
 /* n calls of turtle_stepper_position; `position` rows of rays with no data
  * are left untouched and their data_index is -1 (data_index is mandatory). */

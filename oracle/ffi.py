@@ -184,6 +184,17 @@ class OracleGeometry:
                                    _p(x), _p(y), _p(z), _p(inside))
         return z, inside
 
+    def grid_gradient(self, grid, x, y, fill=-7.0):
+        """(gx, gy, inside); outputs start at `fill` (they are in-out in the
+        reference: untouched when outside or by the map.c:353 slip)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        gx, gy = np.full(x.size, fill), np.full(x.size, fill)
+        inside = np.empty(x.size, dtype=np.int32)
+        lib().orc_grid_gradient_n(C.byref(self.grids[grid]), C.c_long(x.size), _p(x), _p(y),
+                                  _p(gx), _p(gy), _p(inside))
+        return gx, gy, inside
+
     def stack_elevation(self, stack, latitude, longitude):
         lat = np.ascontiguousarray(latitude, dtype=np.float64)
         lon = np.ascontiguousarray(longitude, dtype=np.float64)

@@ -95,6 +95,18 @@ class RefMap:
             z[k], inside[k] = zz.value, ii.value
         return z, inside
 
+    def gradient(self, x, y, fill=-7.0):
+        x = np.asarray(x, dtype=np.float64)
+        gx, gy = np.full(x.size, fill), np.full(x.size, fill)
+        inside = np.zeros(x.size, dtype=np.int32)
+        f = lib().turtle_map_gradient
+        a, b, ii = D(), D(), C.c_int()
+        for k in range(x.size):
+            a.value = b.value = fill
+            f(self.h, D(x[k]), D(y[k]), C.byref(a), C.byref(b), C.byref(ii))
+            gx[k], gy[k], inside[k] = a.value, b.value, ii.value
+        return gx, gy, inside
+
     def node(self, ix, iy):
         x, y, z = D(), D(), D()
         rc = lib().turtle_map_node(self.h, ix, iy, C.byref(x), C.byref(y), C.byref(z))
@@ -126,6 +138,18 @@ class RefStack:
             f(self.h, D(lat[k]), D(longitude[k]), C.byref(zz), C.byref(ii))
             z[k], inside[k] = zz.value, ii.value
         return z, inside
+
+    def gradient(self, latitude, longitude, fill=-7.0):
+        lat = np.asarray(latitude, dtype=np.float64)
+        glat, glon = np.full(lat.size, fill), np.full(lat.size, fill)
+        inside = np.zeros(lat.size, dtype=np.int32)
+        f = lib().turtle_stack_gradient
+        a, b, ii = D(), D(), C.c_int()
+        for k in range(lat.size):
+            a.value = b.value = fill
+            f(self.h, D(lat[k]), D(longitude[k]), C.byref(a), C.byref(b), C.byref(ii))
+            glat[k], glon[k], inside[k] = a.value, b.value, ii.value
+        return glat, glon, inside
 
     def destroy(self):
         lib().turtle_stack_destroy(C.byref(self.h))

@@ -208,6 +208,92 @@ int orc_grid_elevation(const struct orc_grid * g, double x, double y, double * z
         return 1;
 }
 
+
+/* map.c:280-378.  Mirrors the reference as it is, including its slip at
+ * map.c:352-353: for a point in the first half-row of the grid (iy == 0,
+ * hy <= 0.5) the y-gradient is stored into *gx and *gy is left untouched. */
+int orc_grid_gradient(
+    const struct orc_grid * g, double x, double y, double * gx, double * gy)
+{
+        if (isnan(x) || isnan(y)) return 0;
+        double hx = (x - g->x0) / g->dx;
+        double hy = (y - g->y0) / g->dy;
+        if ((hx > g->nx - 1) || (hx < 0) || (hy > g->ny - 1) || (hy < 0)) return 0;
+        int ix = (int)hx;
+        int iy = (int)hy;
+        if (ix == g->nx - 1) {
+                ix--;
+                hx = 1.;
+        } else
+                hx -= ix;
+        if (iy == g->ny - 1) {
+                iy--;
+                hy = 1.;
+        } else
+                hy -= iy;
+        const double z00 = orc_grid_node(g, ix, iy);
+        const double z10 = orc_grid_node(g, ix + 1, iy);
+        const double z01 = orc_grid_node(g, ix, iy + 1);
+        const double z11 = orc_grid_node(g, ix + 1, iy + 1);
+
+        if (hx <= 0.5) { /* map.c:324-335 */
+                const double gx1 = (z10 - z00) * (1. - hy) + (z11 - z01) * hy;
+                if (ix == 0) {
+                        *gx = gx1 / g->dx;
+                } else {
+                        const double z_10 = orc_grid_node(g, ix - 1, iy);
+                        const double z_11 = orc_grid_node(g, ix - 1, iy + 1);
+                        const double gx0 = (z00 - z_10) * (1. - hy) + (z01 - z_11) * hy;
+                        const double ax = hx + 0.5;
+                        *gx = (gx0 * (1. - ax) + gx1 * ax) / g->dx;
+                }
+        } else { /* map.c:336-348 */
+                const double gx0 = (z10 - z00) * (1. - hy) + (z11 - z01) * hy;
+                if (ix == g->nx - 2) {
+                        *gx = gx0 / g->dx;
+                } else {
+                        const double z20 = orc_grid_node(g, ix + 2, iy);
+                        const double z21 = orc_grid_node(g, ix + 2, iy + 1);
+                        const double gx1 = (z20 - z10) * (1. - hy) + (z21 - z11) * hy;
+                        const double ax = hx - 0.5;
+                        *gx = (gx0 * (1. - ax) + gx1 * ax) / g->dx;
+                }
+        }
+
+        if (hy <= 0.5) { /* map.c:350-361 */
+                const double gy1 = (z01 - z00) * (1. - hx) + (z11 - z10) * hx;
+                if (iy == 0) {
+                        *gx = gy1 / g->dy; /* sic, map.c:353 */
+                } else {
+                        const double z0_1 = orc_grid_node(g, ix, iy - 1);
+                        const double z1_1 = orc_grid_node(g, ix + 1, iy - 1);
+                        const double gy0 = (z00 - z0_1) * (1. - hx) + (z10 - z1_1) * hx;
+                        const double ay = hy + 0.5;
+                        *gy = (gy0 * (1. - ay) + gy1 * ay) / g->dy;
+                }
+        } else { /* map.c:362-374 */
+                const double gy0 = (z01 - z00) * (1. - hx) + (z11 - z10) * hx;
+                if (iy == g->ny - 2) {
+                        *gy = gy0 / g->dy;
+                } else {
+                        const double z02 = orc_grid_node(g, ix, iy + 2);
+                        const double z12 = orc_grid_node(g, ix + 1, iy + 2);
+                        const double gy1 = (z02 - z01) * (1. - hx) + (z12 - z11) * hx;
+                        const double ay = hy - 0.5;
+                        *gy = (gy0 * (1. - ay) + gy1 * ay) / g->dy;
+                }
+        }
+        return 1;
+}
+
+void orc_grid_gradient_n(const struct orc_grid * grid, long n, const double * x,
+    const double * y, double * gx, double * gy, int * inside)
+{
+        long r;
+        for (r = 0; r < n; r++)
+                inside[r] = orc_grid_gradient(grid, x[r], y[r], gx + r, gy + r);
+}
+
 /* ---- tile directory, all tiles resident -------------------------------- */
 
 /* half-open membership test used for resident tiles, stack.c:307-311,:320-321 */

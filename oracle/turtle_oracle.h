@@ -106,6 +106,11 @@ void orc_ecef_to_horizontal(double latitude, double longitude,
 /* map.c:229-277; returns inside (0/1) */
 int orc_grid_elevation(const struct orc_grid * grid, double x, double y,
     double * z);
+/* map.c:280-378 (as is, slip at :353 included); gx/gy are in-out */
+int orc_grid_gradient(const struct orc_grid * grid, double x, double y,
+    double * gx, double * gy);
+void orc_grid_gradient_n(const struct orc_grid * grid, long n,
+    const double * x, const double * y, double * gx, double * gy, int * inside);
 /* map.c:208-226 (node value only) */
 double orc_grid_node(const struct orc_grid * grid, int ix, int iy);
 /* stack.c:300-361 + :399-450 with all tiles resident; returns inside */

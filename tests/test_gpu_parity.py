@@ -478,3 +478,19 @@ def test_scattering_walk_against_oracle(math):
     assert flips <= 3, flips
     st.destroy()
     m.destroy()
+
+
+def test_gradient_bit_exact(golden, tmp_path):
+    """turtle_map_gradient / turtle_stack_gradient [ref map.c:280-392,
+    stack.c:364-388]: +,-,*,/ only, so bit-exact, slip at map.c:353 included."""
+    g = golden("gradient")
+    m = TA.Map.create(g["nodes"], T.C1_X, T.C1_Y, T.C1_Z)
+    gx, gy, inside = m.gradient(g["x"], g["y"], fill=-7.0)
+    assert np.array_equal(inside, g["inside"])
+    assert np.array_equal(gx, g["gx"]) and np.array_equal(gy, g["gy"])
+    m.destroy()
+    stack = B.mosaic(tmp_path, [(45, 3), (45, 4), (46, 3)], 1201)
+    glat, glon, sin = stack.gradient(g["lat"], g["lon"], fill=-7.0)
+    assert np.array_equal(sin, g["sinside"])
+    assert np.array_equal(glat, g["glat"]) and np.array_equal(glon, g["glon"])
+    stack.destroy()

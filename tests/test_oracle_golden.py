@@ -157,3 +157,13 @@ def test_g6_layers(golden):
         _check_trace(t, g, name + "_t")
         t2 = geo.trace(t["position"], g[name + "_tdir"])
         _check_trace(t2, g, name + "_t2")
+
+
+def test_g8_gradient(golden):
+    """turtle_map_gradient incl. the slip at map.c:353 (13 rows of the fixture)."""
+    g = golden("gradient")
+    geo = O.OracleGeometry(grids=[O.default_grid(g["nodes"], T.C1_X, T.C1_Y, T.C1_Z)],
+                           layers=[[(O.MAP, 0, 0.0)]])
+    gx, gy, inside = geo.grid_gradient(0, g["x"], g["y"])
+    assert eq(inside, g["inside"]) and eq(gx, g["gx"]) and eq(gy, g["gy"])
+    assert ((g["gy"] == -7.0) & (g["inside"] == 1)).sum() > 0  # the slip is exercised

@@ -297,6 +297,19 @@ class Map:
                                             _ptr(inside), sp))
         return z, inside
 
+    def gradient(self, x, y, fill=0.0):
+        """Batch gradient -> (gx, gy, inside); outputs start at `fill`."""
+        sp = _space_of(x, y)
+        x, y = _as(x, sp), _as(y, sp)
+        n = x.shape[0]
+        gx, gy = _new((n,), sp, like=x), _new((n,), sp, like=x)
+        gx[...] = fill
+        gy[...] = fill
+        inside = _new((n,), sp, np.int32, like=x)
+        _check(lib().turtle_map_gradient_n(self.h, C.c_long(n), _ptr(x), _ptr(y), _ptr(gx),
+                                           _ptr(gy), _ptr(inside), sp))
+        return gx, gy, inside
+
     def elevation_scalar(self, x, y, want_inside=True):
         z, inside = C.c_double(-12345.0), C.c_int(-1)
         rc = lib().turtle_map_elevation(self.h, C.c_double(x), C.c_double(y), C.byref(z),
@@ -334,6 +347,18 @@ class Stack:
         _check(lib().turtle_stack_elevation_n(self.h, C.c_long(n), _ptr(la), _ptr(lo),
                                               _ptr(z), _ptr(inside), sp))
         return z, inside
+
+    def gradient(self, latitude, longitude, fill=0.0):
+        sp = _space_of(latitude, longitude)
+        la, lo = _as(latitude, sp), _as(longitude, sp)
+        n = la.shape[0]
+        glat, glon = _new((n,), sp, like=la), _new((n,), sp, like=la)
+        glat[...] = fill
+        glon[...] = fill
+        inside = _new((n,), sp, np.int32, like=la)
+        _check(lib().turtle_stack_gradient_n(self.h, C.c_long(n), _ptr(la), _ptr(lo),
+                                             _ptr(glat), _ptr(glon), _ptr(inside), sp))
+        return glat, glon, inside
 
     def elevation_scalar(self, latitude, longitude, want_inside=True):
         z, inside = C.c_double(-12345.0), C.c_int(-1)

@@ -480,6 +480,76 @@ __device__ __forceinline__ bool d_grid_elevation(
         return true;
 }
 
+/* [ref map.c:280-378], as it is -- including the slip at map.c:352-353: for a
+ * point in the grid's first half-row (iy == 0, hy <= 0.5) the y-gradient lands
+ * in gx and gy is left untouched.  gx, gy are therefore in-out. */
+__device__ __forceinline__ bool d_grid_gradient(
+    const tamd_grid & g, double x, double y, double & gx, double & gy)
+{
+        if (isnan(x) || isnan(y)) return false;
+        double hx = (x - g.x0) / g.dx;
+        double hy = (y - g.y0) / g.dy;
+        if ((hx > g.nx - 1) || (hx < 0) || (hy > g.ny - 1) || (hy < 0)) return false;
+        int ix = (int)hx;
+        int iy = (int)hy;
+        if (ix == g.nx - 1) {
+                ix--;
+                hx = 1.;
+        } else
+                hx -= ix;
+        if (iy == g.ny - 1) {
+                iy--;
+                hy = 1.;
+        } else
+                hy -= iy;
+        const double z00 = d_node(g, ix, iy), z10 = d_node(g, ix + 1, iy);
+        const double z01 = d_node(g, ix, iy + 1), z11 = d_node(g, ix + 1, iy + 1);
+
+        if (hx <= 0.5) { /* [ref map.c:324-335] */
+                const double gx1 = (z10 - z00) * (1. - hy) + (z11 - z01) * hy;
+                if (ix == 0) {
+                        gx = gx1 / g.dx;
+                } else {
+                        const double z_10 = d_node(g, ix - 1, iy), z_11 = d_node(g, ix - 1, iy + 1);
+                        const double gx0 = (z00 - z_10) * (1. - hy) + (z01 - z_11) * hy;
+                        const double ax = hx + 0.5;
+                        gx = (gx0 * (1. - ax) + gx1 * ax) / g.dx;
+                }
+        } else { /* [ref map.c:336-348] */
+                const double gx0 = (z10 - z00) * (1. - hy) + (z11 - z01) * hy;
+                if (ix == g.nx - 2) {
+                        gx = gx0 / g.dx;
+                } else {
+                        const double z20 = d_node(g, ix + 2, iy), z21 = d_node(g, ix + 2, iy + 1);
+                        const double gx1 = (z20 - z10) * (1. - hy) + (z21 - z11) * hy;
+                        const double ax = hx - 0.5;
+                        gx = (gx0 * (1. - ax) + gx1 * ax) / g.dx;
+                }
+        }
+        if (hy <= 0.5) { /* [ref map.c:350-361] */
+                const double gy1 = (z01 - z00) * (1. - hx) + (z11 - z10) * hx;
+                if (iy == 0) {
+                        gx = gy1 / g.dy; /* sic [ref map.c:353] */
+                } else {
+                        const double z0_1 = d_node(g, ix, iy - 1), z1_1 = d_node(g, ix + 1, iy - 1);
+                        const double gy0 = (z00 - z0_1) * (1. - hx) + (z10 - z1_1) * hx;
+                        const double ay = hy + 0.5;
+                        gy = (gy0 * (1. - ay) + gy1 * ay) / g.dy;
+                }
+        } else { /* [ref map.c:362-374] */
+                const double gy0 = (z01 - z00) * (1. - hx) + (z11 - z10) * hx;
+                if (iy == g.ny - 2) {
+                        gy = gy0 / g.dy;
+                } else {
+                        const double z02 = d_node(g, ix, iy + 2), z12 = d_node(g, ix + 1, iy + 2);
+                        const double gy1 = (z02 - z01) * (1. - hx) + (z12 - z11) * hx;
+                        const double ay = hy - 0.5;
+                        gy = (gy0 * (1. - ay) + gy1 * ay) / g.dy;
+                }
+        }
+        return true;
+}
+
 /* ---- tile directory --------------------------------------------------- */
 
 /* half-open box of a resident tile [ref stack.c:307-311, :320-321] */
@@ -498,17 +568,17 @@ __device__ __forceinline__ bool d_tile_holds(
  * the directory formula proposes the tile first (O(1)); its neighbours are
  * consulted only when rounding at a seam makes the box test disagree, which
  * reproduces the list scan's answer without the list. */
-template <bool FAST = false>
-__device__ __forceinline__ bool d_stack_elevation(const tamd_view & v,
-    const tamd_stack & st, double latitude, double longitude, double & z)
+/* The tile of a stack that answers for a point, or -1 [ref stack.c:300-335,
+ * :413-424]: see d_stack_elevation. */
+__device__ __forceinline__ int d_stack_tile(const tamd_view & v, const tamd_stack & st,
+    double latitude, double longitude)
 {
-        z = 0.;
         const double fx = (longitude - st.lon0) / st.dlon;
         const double fy = (latitude - st.lat0) / st.dlat;
         /* no tile box reaches further than one cell from the directory */
         if (!((fx > -1.5) && (fx < st.nlon + 1.5) && (fy > -1.5) &&
                 (fy < st.nlat + 1.5)))
-                return false;
+                return -1;
         const int cx = min(max((int)fx, 0), st.nlon - 1);
         const int cy = min(max((int)fy, 0), st.nlat - 1);
         const int * tiles = v.tiles + st.tile_first;
@@ -528,12 +598,21 @@ __device__ __forceinline__ bool d_stack_elevation(const tamd_view & v,
                         }
                 }
                 if (tile < 0) { /* [ref stack.c:413-424] */
-                        if ((longitude < st.lon0) || (latitude < st.lat0)) return false;
-                        if (!(fx < st.nlon) || !(fy < st.nlat)) return false;
+                        if ((longitude < st.lon0) || (latitude < st.lat0)) return -1;
+                        if (!(fx < st.nlon) || !(fy < st.nlat)) return -1;
                         tile = tiles[(int)fy * st.nlon + (int)fx];
-                        if (tile < 0) return false;
                 }
         }
+        return tile;
+}
+
+template <bool FAST = false>
+__device__ __forceinline__ bool d_stack_elevation(const tamd_view & v,
+    const tamd_stack & st, double latitude, double longitude, double & z)
+{
+        z = 0.;
+        const int tile = d_stack_tile(v, st, latitude, longitude);
+        if (tile < 0) return false;
         const bool inside = d_grid_elevation<FAST>(v.grids[tile], longitude, latitude, z);
         if (!inside) z = 0.;
         return inside;
@@ -822,6 +901,36 @@ __global__ void k_elevation(tamd_view v, long n, const double * __restrict__ a,
                 /* an outside point leaves a MAP's z untouched in the reference
                  * and zeroes a STACK's; report 0 for both */
                 z[r] = in ? zz : 0.;
+                inside[r] = in ? 1 : 0;
+        }
+}
+
+/* Gradient of n points on the view's first meta: a MAP takes (x, y) and
+ * returns (gx, gy) [ref map.c:387-392]; a STACK takes (latitude, longitude)
+ * and returns (glat, glon) [ref stack.c:364-388].  Outputs are in-out. */
+__global__ void k_gradient(tamd_view v, long n, const double * __restrict__ a,
+    const double * __restrict__ b, double * __restrict__ ga, double * __restrict__ gb,
+    int * __restrict__ inside)
+{
+        const tamd_meta mt = v.metas[0];
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
+             r += (long)gridDim.x * blockDim.x) {
+                bool in = false;
+                if (mt.kind == TAMD_MAP) {
+                        double gx = ga[r], gy = gb[r];
+                        in = d_grid_gradient(v.grids[mt.src], a[r], b[r], gx, gy);
+                        ga[r] = gx, gb[r] = gy;
+                } else {
+                        const int tile = d_stack_tile(v, v.stacks[mt.src], a[r], b[r]);
+                        if (tile < 0) {
+                                ga[r] = gb[r] = 0.; /* [ref stack.c:378-382] */
+                        } else {
+                                double glat = ga[r], glon = gb[r];
+                                /* x = longitude, y = latitude; gx -> glon, gy -> glat */
+                                in = d_grid_gradient(v.grids[tile], b[r], a[r], glon, glat);
+                                ga[r] = glat, gb[r] = glon;
+                        }
+                }
                 inside[r] = in ? 1 : 0;
         }
 }
@@ -1620,6 +1729,17 @@ extern "C" int tamd_k_elevation(struct tamd_view view, long n, const double * a,
         hipLaunchKernelGGL(k_elevation, dim3(grid_for(n, 256)), dim3(256), 0, g_stream,
             view, n, a, b, z, inside);
         LAUNCH_CHECK("k_elevation");
+        return 0;
+}
+
+extern "C" int tamd_k_gradient(struct tamd_view view, long n, const double * a,
+    const double * b, double * ga, double * gb, int * inside)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        hipLaunchKernelGGL(k_gradient, dim3(grid_for(n, 256)), dim3(256), 0, g_stream, view,
+            n, a, b, ga, gb, inside);
+        LAUNCH_CHECK("k_gradient");
         return 0;
 }
 

@@ -69,6 +69,10 @@ const char * turtle_error_function(turtle_function_t * caller)
         NAME(turtle_map_destroy);
         NAME(turtle_map_elevation);
         NAME(turtle_map_fill);
+        NAME(turtle_map_gradient);
+        NAME(turtle_map_gradient_n);
+        NAME(turtle_stack_gradient);
+        NAME(turtle_stack_gradient_n);
         NAME(turtle_map_load);
         NAME(turtle_map_meta);
         NAME(turtle_map_node);

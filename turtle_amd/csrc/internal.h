@@ -131,6 +131,10 @@ int tamd_k_ecef_to_horizontal(long n, const double * lat, const double * lon,
 /* elevation of n points on metas[0] of the view (a MAP or a STACK entry) */
 int tamd_k_elevation(struct tamd_view view, long n, const double * a,
     const double * b, double * z, int * inside);
+/* gradient of n points on metas[0]: MAP (x, y) -> (gx, gy); STACK (lat, lon)
+ * -> (glat, glon); ga/gb are in-out */
+int tamd_k_gradient(struct tamd_view view, long n, const double * a,
+    const double * b, double * ga, double * gb, int * inside);
 int tamd_k_position(struct tamd_view view, long n, const double * lat,
     const double * lon, const double * height, int layer, double * pos,
     int * data_index);

@@ -294,3 +294,53 @@ enum turtle_return turtle_map_elevation(const struct turtle_map * map, double x,
                     TURTLE_RETURN_DOMAIN_ERROR, "point is outside of map");
         return TURTLE_RETURN_SUCCESS;
 }
+
+/* ---- gradient [ref map.c:280-392] ------------------------------------------ */
+
+static int map_gradient_n(struct turtle_map * map, long n, const double * x,
+    const double * y, double * gx, double * gy, int * inside, int space)
+{
+        struct tamd_stage st;
+        struct tamd_view view;
+        void *dx, *dy, *dgx, *dgy, *di;
+        const size_t nb = (size_t)n * sizeof(double);
+        if (tamd_stage_begin(&st, space, 4 * nb + n * sizeof(int) + 4096)) return 1;
+        if (space == TURTLE_AMD_DEVICE) tamd_scratch_reset();
+        if (map_view(map, &view)) return 1;
+        /* gx, gy are in-out: a point outside the map leaves them untouched */
+        if (tamd_stage_in(&st, x, nb, &dx) || tamd_stage_in(&st, y, nb, &dy) ||
+            tamd_stage_in(&st, gx, nb, &dgx) || tamd_stage_in(&st, gy, nb, &dgy) ||
+            tamd_stage_out(&st, inside, n * sizeof(int), &di))
+                return 1;
+        if (tamd_k_gradient(view, n, dx, dy, dgx, dgy, di)) return 1;
+        if (tamd_stage_fetch(&st, gx, nb, dgx) || tamd_stage_fetch(&st, gy, nb, dgy) ||
+            tamd_stage_fetch(&st, inside, n * sizeof(int), di))
+                return 1;
+        return tamd_dev_sync();
+}
+
+enum turtle_return turtle_map_gradient_n(const struct turtle_map * map, long n,
+    const double * x, const double * y, double * gx, double * gy, int * inside, int space)
+{
+        TAMD_ERROR_INIT(&turtle_map_gradient_n);
+        if ((map == NULL) || (inside == NULL) || (gx == NULL) || (gy == NULL))
+                return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
+        if (map_gradient_n((struct turtle_map *)map, n, x, y, gx, gy, inside, space))
+                return TAMD_RAISE_DEVICE();
+        return TURTLE_RETURN_SUCCESS;
+}
+
+/* [ref map.c:387-392] */
+enum turtle_return turtle_map_gradient(const struct turtle_map * map, double x, double y,
+    double * gx, double * gy, int * inside)
+{
+        TAMD_ERROR_INIT(&turtle_map_gradient);
+        int in = 0;
+        if (map_gradient_n((struct turtle_map *)map, 1, &x, &y, gx, gy, &in, TURTLE_AMD_HOST))
+                return TAMD_RAISE_DEVICE();
+        if (inside != NULL)
+                *inside = in;
+        else if (!in)
+                return TAMD_RAISE(TURTLE_RETURN_DOMAIN_ERROR, "point is outside of map");
+        return TURTLE_RETURN_SUCCESS;
+}

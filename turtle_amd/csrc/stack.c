@@ -352,3 +352,69 @@ enum turtle_return turtle_stack_elevation(struct turtle_stack * stack,
             (turtle_function_t *)&turtle_stack_elevation, latitude, longitude, elevation,
             inside);
 }
+
+/* ---- gradient [ref stack.c:364-388] ----------------------------------------- */
+
+static int stack_gradient_n(struct turtle_stack * stack, long n, const double * latitude,
+    const double * longitude, double * glat, double * glon, int * inside, int space,
+    char * message, size_t size)
+{
+        struct tamd_stage st;
+        struct tamd_view view;
+        void *da, *db, *dga, *dgb, *di;
+        const size_t nb = (size_t)n * sizeof(double);
+        const size_t tables =
+            (size_t)(stack->latitude_n * stack->longitude_n + 2) * 128 + 4096;
+        if (tamd_stage_begin(&st, space, 4 * nb + n * sizeof(int) + tables)) return -1;
+        if (space == TURTLE_AMD_DEVICE) {
+                void * all;
+                tamd_scratch_reset();
+                if (tamd_scratch_get(&all, tables)) return -1;
+                tamd_scratch_reset();
+        }
+        const int rc = stack_view(stack, &view, message, size);
+        if (rc != 0) return rc;
+        if (tamd_stage_in(&st, latitude, nb, &da) || tamd_stage_in(&st, longitude, nb, &db) ||
+            tamd_stage_in(&st, glat, nb, &dga) || tamd_stage_in(&st, glon, nb, &dgb) ||
+            tamd_stage_out(&st, inside, n * sizeof(int), &di))
+                return -1;
+        if (tamd_k_gradient(view, n, da, db, dga, dgb, di)) return -1;
+        if (tamd_stage_fetch(&st, glat, nb, dga) || tamd_stage_fetch(&st, glon, nb, dgb) ||
+            tamd_stage_fetch(&st, inside, n * sizeof(int), di))
+                return -1;
+        return tamd_dev_sync() ? -1 : 0;
+}
+
+enum turtle_return turtle_stack_gradient_n(struct turtle_stack * stack, long n,
+    const double * latitude, const double * longitude, double * glat, double * glon,
+    int * inside, int space)
+{
+        TAMD_ERROR_INIT(&turtle_stack_gradient_n);
+        if ((stack == NULL) || (inside == NULL) || (glat == NULL) || (glon == NULL))
+                return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
+        char message[4200];
+        const int rc = stack_gradient_n(stack, n, latitude, longitude, glat, glon, inside,
+            space, message, sizeof(message));
+        if (rc < 0) return TAMD_RAISE_DEVICE();
+        if (rc > 0) return TAMD_RAISE((enum turtle_return)rc, "%s", message);
+        return TURTLE_RETURN_SUCCESS;
+}
+
+enum turtle_return turtle_stack_gradient(struct turtle_stack * stack, double latitude,
+    double longitude, double * glat, double * glon, int * inside)
+{
+        TAMD_ERROR_INIT(&turtle_stack_gradient);
+        if (inside != NULL) *inside = 0;
+        int in = 0;
+        char message[4200];
+        const int rc = stack_gradient_n(stack, 1, &latitude, &longitude, glat, glon, &in,
+            TURTLE_AMD_HOST, message, sizeof(message));
+        if (rc < 0) return TAMD_RAISE_DEVICE();
+        if (rc > 0) return TAMD_RAISE((enum turtle_return)rc, "%s", message);
+        if (inside != NULL)
+                *inside = in;
+        else if (!in)
+                return TAMD_RAISE(TURTLE_RETURN_PATH_ERROR,
+                    "missing elevation data in `%s'", stack->root);
+        return TURTLE_RETURN_SUCCESS;
+}
