@@ -31,12 +31,33 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+class Proj(C.Structure):
+    _fields_ = [("type", C.c_int), ("lambert_tag", C.c_int),
+                ("longitude_0", C.c_double), ("hemisphere", C.c_int)]
+
+
+LAMBERT_TAGS = ["I", "II", "IIe", "III", "IV", "93"]
+
+
+def parse_projection(name):
+    """'Lambert 93', 'UTM 31N', 'UTM 3.5N' -> Proj (projection.c:98-171)."""
+    if name is None:
+        return Proj(-1, 0, 0.0, 0)
+    words = name.split()
+    if words[0] == "Lambert":
+        return Proj(0, LAMBERT_TAGS.index(words[1]), 0.0, 0)
+    spec = words[1]
+    hemi = 1 if spec[-1] == "N" else -1
+    lon0 = float(spec[:-1]) if "." in spec else 6.0 * int(spec[:-1]) - 183.0
+    return Proj(1, 0, lon0, hemi)
+
+
 class Grid(C.Structure):
     _fields_ = [("nx", C.c_int), ("ny", C.c_int),
                 ("x0", C.c_double), ("y0", C.c_double),
                 ("dx", C.c_double), ("dy", C.c_double),
                 ("z0", C.c_double), ("dz", C.c_double),
-                ("layout", C.c_int), ("data", C.c_void_p)]
+                ("layout", C.c_int), ("data", C.c_void_p), ("proj", Proj)]
 
 
 class Stack(C.Structure):
@@ -102,7 +123,7 @@ class OracleGeometry:
             self._keep.append(data)
             self.grids[i] = Grid(g["nx"], g["ny"], g["x0"], g["y0"], g["dx"],
                                  g["dy"], g["z0"], g["dz"], g["layout"],
-                                 data.ctypes.data)
+                                 data.ctypes.data, parse_projection(g.get("projection")))
         self.stacks = (Stack * max(1, len(stacks)))()
         for i, s in enumerate(stacks):
             tile = np.ascontiguousarray(s["tile"], dtype=np.int32).reshape(-1)
@@ -205,6 +226,24 @@ class OracleGeometry:
         return z, inside
 
 
+def project(name, latitude, longitude):
+    lat = np.ascontiguousarray(latitude, dtype=np.float64)
+    lon = np.ascontiguousarray(longitude, dtype=np.float64)
+    x, y = np.empty(lat.size), np.empty(lat.size)
+    pr = parse_projection(name)
+    lib().orc_project_n(C.byref(pr), C.c_long(lat.size), _p(lat), _p(lon), _p(x), _p(y))
+    return x, y
+
+
+def unproject(name, x, y):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    lat, lon = np.empty(x.size), np.empty(x.size)
+    pr = parse_projection(name)
+    lib().orc_unproject_n(C.byref(pr), C.c_long(x.size), _p(x), _p(y), _p(lat), _p(lon))
+    return lat, lon
+
+
 def ecef_to_geodetic(ecef):
     e = np.ascontiguousarray(ecef, dtype=np.float64).reshape(-1, 3)
     n = e.shape[0]
@@ -250,11 +289,11 @@ def hgt_grid(lat0, lon0, nodes_s2n):
                 dy=1.0 / (n - 1), z0=-32767.0, dz=1.0, layout=LAYOUT_HGT, data=raw)
 
 
-def default_grid(nodes_s2n, x, y, z):
+def default_grid(nodes_s2n, x, y, z, projection=None):
     """Grid dict as turtle_map_create + turtle_map_fill would hold it (map.c:54-99)."""
     ny, nx = nodes_s2n.shape
     dx = (x[1] - x[0]) / (nx - 1) if nx > 1 else 0.0
     dy = (y[1] - y[0]) / (ny - 1) if ny > 1 else 0.0
     return dict(nx=nx, ny=ny, x0=float(x[0]), y0=float(y[0]), dx=dx, dy=dy,
                 z0=float(z[0]), dz=(z[1] - z[0]) / 65535, layout=LAYOUT_DEFAULT,
-                data=default_grid_raw(nodes_s2n, z[0], z[1]))
+                data=default_grid_raw(nodes_s2n, z[0], z[1]), projection=projection)

@@ -62,11 +62,12 @@ class RefMap:
         self.h = handle
 
     @classmethod
-    def create(cls, nodes_s2n, x, y, z):
+    def create(cls, nodes_s2n, x, y, z, projection=None):
         ny, nx = nodes_s2n.shape
         info = MapInfo(nx, ny, (D * 2)(*x), (D * 2)(*y), (D * 2)(*z), None)
         h = C.c_void_p()
-        rc = lib().turtle_map_create(C.byref(h), C.byref(info), None)
+        rc = lib().turtle_map_create(C.byref(h), C.byref(info),
+                                     projection.encode() if projection else None)
         assert rc == 0, errors()
         m = cls(h)
         fill = lib().turtle_map_fill
@@ -294,3 +295,33 @@ def ecef_to_horizontal(lat, lon, direction):
         f(D(lat[k]), D(lon[k]), (D * 3)(*d[k]), C.byref(a), C.byref(e))
         az[k], el[k] = a.value, e.value
     return az, el
+
+
+class RefProjection:
+    def __init__(self, name):
+        self.h = C.c_void_p()
+        rc = lib().turtle_projection_create(C.byref(self.h), name.encode())
+        assert rc == 0, errors()
+
+    def project(self, lat, lon):
+        lat = np.asarray(lat, dtype=np.float64)
+        x, y = np.empty(lat.size), np.empty(lat.size)
+        f = lib().turtle_projection_project
+        a, b = D(), D()
+        for k in range(lat.size):
+            f(self.h, D(lat[k]), D(lon[k]), C.byref(a), C.byref(b))
+            x[k], y[k] = a.value, b.value
+        return x, y
+
+    def unproject(self, x, y):
+        x = np.asarray(x, dtype=np.float64)
+        lat, lon = np.empty(x.size), np.empty(x.size)
+        f = lib().turtle_projection_unproject
+        a, b = D(), D()
+        for k in range(x.size):
+            f(self.h, D(x[k]), D(y[k]), C.byref(a), C.byref(b))
+            lat[k], lon[k] = a.value, b.value
+        return lat, lon
+
+    def destroy(self):
+        lib().turtle_projection_destroy(C.byref(self.h))

@@ -161,7 +161,137 @@ void orc_ecef_to_horizontal(double latitude, double longitude,
         }
 }
 
+/* ---- projections -------------------------------------------------------- */
+
+/* projection.c:238-244 */
+static double lambert_latitude_to_iso(double latitude, double e)
+{
+        const double phi = latitude * ORC_PI / 180.;
+        const double s = sin(phi);
+        return log(tan(0.25 * ORC_PI + 0.5 * phi) * pow((1. - e * s) / (1. + e * s), 0.5 * e));
+}
+
+/* projection.c:253-268 */
+static double lambert_iso_to_latitude(double L, double e)
+{
+        const double epsilon = FLT_EPSILON;
+        const double eL = exp(L);
+        double phi0 = 2. * atan(eL) - 0.5 * ORC_PI;
+        for (;;) {
+                const double s = sin(phi0);
+                double phi1 =
+                    2. * atan(pow((1. + e * s) / (1. - e * s), 0.5 * e) * eL) - 0.5 * ORC_PI;
+                if (fabs(phi1 - phi0) <= epsilon) return phi1 / ORC_PI * 180.;
+                phi0 = phi1;
+        }
+}
+
+/* projection.c:329-349: e, n, c, lambda_c, xs, ys */
+static const double LAMBERT[6][6] = {
+        { 0.08248325676, 0.7604059656, 11603796.98, 0.04079234433, 600000.0, 5657616.674 },
+        { 0.08248325676, 0.7289686274, 11745793.39, 0.04079234433, 600000.0, 6199695.768 },
+        { 0.08248325676, 0.7289686274, 11745793.39, 0.04079234433, 600000.0, 8199695.768 },
+        { 0.08248325676, 0.6959127966, 11947992.52, 0.04079234433, 600000.0, 6791905.085 },
+        { 0.08248325676, 0.6712679322, 12136281.99, 0.04079234433, 234.358, 7239161.542 },
+        { 0.08181919112, 0.7253743710, 11755528.70, 0.05235987756, 700000.0, 12657560.145 }
+};
+
+void orc_project(const struct orc_proj * proj, double latitude, double longitude,
+    double * x, double * y)
+{
+        if (proj->type == ORC_PROJ_LAMBERT) { /* projection.c:286-295 */
+                const double * P = LAMBERT[proj->lambert_tag];
+                const double L = lambert_latitude_to_iso(latitude, P[0]);
+                const double cenL = P[2] * exp(-P[1] * L);
+                const double lambda = longitude / 180. * ORC_PI;
+                const double theta = P[1] * (lambda - P[3]);
+                *x = P[4] + cenL * sin(theta);
+                *y = P[5] - cenL * cos(theta);
+                return;
+        }
+        /* projection.c:377-408 */
+        const double a = 6378.137E+03;
+        const double f = 1. / 298.257223563;
+        const double E0 = 5E+05;
+        const double N0 = (proj->hemisphere > 0) ? 0. : 1E+07;
+        const double k0 = 0.9996;
+        const double n = f / (2. - f);
+        const double A = a / (1. + n) * (1. + n * n * (0.25 + 0.0625 * n * n));
+        const double alpha[3] = { n * (0.5 + n * (-2. / 3. + 5. / 16. * n)),
+                n * n * (13. / 48. - 3. / 5. * n), 61. / 240. * n * n * n };
+        const double c = 2. * sqrt(n) / (1. + n);
+        const double s = sin(latitude * ORC_PI / 180.);
+        const double t = sinh(atanh(s) - c * atanh(c * s));
+        const double dl = (longitude - proj->longitude_0) * ORC_PI / 180.;
+        const double zeta = atan2(t, cos(dl));
+        const double eta = atanh(sin(dl) / sqrt(1. + t * t));
+        double xs = 0., ys = 0.;
+        int i;
+        for (i = 0; i < 3; i++) {
+                xs += alpha[i] * cos(2. * (i + 1) * zeta) * sinh(2. * (i + 1) * eta);
+                ys += alpha[i] * sin(2. * (i + 1) * zeta) * cosh(2. * (i + 1) * eta);
+        }
+        *x = E0 + k0 * A * (eta + xs);
+        *y = N0 + k0 * A * (zeta + ys);
+}
+
+void orc_unproject(const struct orc_proj * proj, double x, double y,
+    double * latitude, double * longitude)
+{
+        if (proj->type == ORC_PROJ_LAMBERT) { /* projection.c:304-318 */
+                const double * P = LAMBERT[proj->lambert_tag];
+                const double dx = x - P[4];
+                const double dy = y - P[5];
+                const double R = sqrt(dx * dx + dy * dy);
+                const double gamma = atan2(dx, -dy);
+                *longitude = (P[3] + gamma / P[1]) * 180. / ORC_PI;
+                const double L = -log(R / P[2]) / P[1];
+                *latitude = lambert_iso_to_latitude(L, P[0]);
+                return;
+        }
+        /* projection.c:417-448 */
+        const double a = 6378.137E+03;
+        const double f = 1. / 298.257223563;
+        const double E0 = 5E+05;
+        const double N0 = (proj->hemisphere > 0) ? 0. : 1E+07;
+        const double k0 = 0.9996;
+        const double n = f / (2. - f);
+        const double A = a / (1. + n) * (1. + n * n * (0.25 + 0.0625 * n * n));
+        const double beta[3] = { n * (0.5 + n * (-2. / 3. + 37. / 96. * n)),
+                n * n * (1. / 48. + 1. / 15. * n), 17. / 480. * n * n * n };
+        const double delta[3] = { n * (2. + n * (-2. / 3. - 2. * n)),
+                n * n * (7. / 3. - 8. / 5. * n), 56. / 15. * n * n * n };
+        const double zeta0 = (y - N0) / (k0 * A);
+        const double eta0 = (x - E0) / (k0 * A);
+        double zeta = zeta0, eta = eta0;
+        int i;
+        for (i = 0; i < 3; i++) {
+                zeta -= beta[i] * sin(2. * (i + 1) * zeta0) * cosh(2. * (i + 1) * eta0);
+                eta -= beta[i] * cos(2. * (i + 1) * zeta0) * sinh(2. * (i + 1) * eta0);
+        }
+        const double chi = asin(sin(zeta) / cosh(eta));
+        double s = 0.;
+        for (i = 0; i < 3; i++) s += delta[i] * sin(2. * (i + 1) * chi);
+        *latitude = (chi + s) * 180. / ORC_PI;
+        *longitude = proj->longitude_0 + atan2(sinh(eta), cos(zeta)) * 180. / ORC_PI;
+}
+
+void orc_project_n(const struct orc_proj * proj, long n, const double * latitude,
+    const double * longitude, double * x, double * y)
+{
+        long r;
+        for (r = 0; r < n; r++) orc_project(proj, latitude[r], longitude[r], x + r, y + r);
+}
+
+void orc_unproject_n(const struct orc_proj * proj, long n, const double * x,
+    const double * y, double * latitude, double * longitude)
+{
+        long r;
+        for (r = 0; r < n; r++) orc_unproject(proj, x[r], y[r], latitude + r, longitude + r);
+}
+
 /* ---- single grid ------------------------------------------------------ */
+
 
 /* map.c:41-44 and hgt.c:127-131 */
 double orc_grid_node(const struct orc_grid * g, int ix, int iy)
@@ -434,9 +564,16 @@ static int source_elevation(const struct orc_geometry * geometry,
         case ORC_FLAT: /* stepper.c:252-264 */
                 *z = 0.;
                 return 1;
-        case ORC_MAP: /* stepper.c:240-241: x = longitude, y = latitude */
-                return orc_grid_elevation(
-                    &geometry->grids[m->src], longitude, latitude, z);
+        case ORC_MAP: { /* stepper.c:240-248, :304-315 */
+                const struct orc_grid * g = &geometry->grids[m->src];
+                if (g->proj.type >= 0) {
+                        double x, y;
+                        orc_project(&g->proj, latitude, longitude, &x, &y);
+                        return orc_grid_elevation(g, x, y, z);
+                }
+                /* geodetic grid: x = longitude, y = latitude */
+                return orc_grid_elevation(g, longitude, latitude, z);
+        }
         default: /* stepper.c:223-224 */
                 return orc_stack_elevation(
                     geometry, &geometry->stacks[m->src], latitude, longitude, z);

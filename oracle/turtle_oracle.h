@@ -38,11 +38,22 @@ enum orc_layout {
         ORC_LAYOUT_HGT = 1
 };
 
+/* src/turtle/projection.h:29-46 */
+enum orc_projection { ORC_PROJ_NONE = -1, ORC_PROJ_LAMBERT = 0, ORC_PROJ_UTM = 1 };
+
+struct orc_proj {
+        int type;           /* enum orc_projection */
+        int lambert_tag;    /* 0..5: I, II, IIe, III, IV, 93 */
+        double longitude_0; /* UTM central meridian */
+        int hemisphere;     /* UTM: +1 north, -1 south */
+};
+
 struct orc_grid {
         int nx, ny;
         double x0, y0, dx, dy, z0, dz;
         int layout;            /* enum orc_layout */
         const uint16_t * data; /* nx*ny raw nodes, as the reference stores them */
+        struct orc_proj proj;  /* type < 0: a geodetic grid (x = lon, y = lat) */
 };
 
 /* A tile directory with every tile resident (src/turtle/stack.h:32-49). */
@@ -102,6 +113,16 @@ void orc_ecef_from_horizontal(double latitude, double longitude,
     double azimuth, double elevation, double direction[3]);
 void orc_ecef_to_horizontal(double latitude, double longitude,
     const double direction[3], double * azimuth, double * elevation);
+
+/* projection.c:192-230, :286-295, :377-408 (forward), :304-318, :417-448 (inverse) */
+void orc_project(const struct orc_proj * proj, double latitude, double longitude,
+    double * x, double * y);
+void orc_unproject(const struct orc_proj * proj, double x, double y,
+    double * latitude, double * longitude);
+void orc_project_n(const struct orc_proj * proj, long n, const double * latitude,
+    const double * longitude, double * x, double * y);
+void orc_unproject_n(const struct orc_proj * proj, long n, const double * x,
+    const double * y, double * latitude, double * longitude);
 
 /* map.c:229-277; returns inside (0/1) */
 int orc_grid_elevation(const struct orc_grid * grid, double x, double y,

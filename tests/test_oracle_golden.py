@@ -167,3 +167,43 @@ def test_g8_gradient(golden):
     gx, gy, inside = geo.grid_gradient(0, g["x"], g["y"])
     assert eq(inside, g["inside"]) and eq(gx, g["gx"]) and eq(gy, g["gy"])
     assert ((g["gy"] == -7.0) & (g["inside"] == 1)).sum() > 0  # the slip is exercised
+
+
+UTM_X, UTM_Y, UTM_Z = (495000.0, 497000.0), (5066000.0, 5068000.0), (0.0, 1000.0)
+
+
+def utm_oracle(g, with_geoid):
+    grids = [O.default_grid(g["nodes"], UTM_X, UTM_Y, UTM_Z, projection="UTM 31N")]
+    geoid = -1
+    if with_geoid:
+        grids.append(O.default_grid(g["geoid_nodes"], (0.0, 360.0), (-90.0, 90.0), (-40.0, 40.0)))
+        geoid = 1
+    return O.OracleGeometry(grids=grids, layers=[[(O.FLAT, 0, -5.0), (O.MAP, 0, 0.0)]],
+                            geoid=geoid)
+
+
+def test_g9_projections(golden):
+    """projection.c forward/inverse for the six Lambert variants and UTM."""
+    g = golden("projection")
+    for k, name in enumerate(g["names"]):
+        x, y = O.project(str(name), g[f"p{k}_lat"], g[f"p{k}_lon"])
+        assert eq(x, g[f"p{k}_x"]) and eq(y, g[f"p{k}_y"]), name
+        la, lo = O.unproject(str(name), g[f"p{k}_x"], g[f"p{k}_y"])
+        assert eq(la, g[f"p{k}_ulat"]) and eq(lo, g[f"p{k}_ulon"]), name
+        assert np.abs(la - g[f"p{k}_lat"]).max() < 1e-7  # it is a projection pair
+
+
+def test_g9_projected_map_in_the_stepper(golden):
+    """stepper.c:65-83, :243-248, :304-311: a UTM map under the stepper."""
+    g = golden("projection")
+    for name in ("nogeoid", "geoid"):
+        geo = utm_oracle(g, name == "geoid")
+        pos, di = geo.position(g[name + "_lat"], g[name + "_lon"], 150.0)
+        assert eq(pos, g[name + "_pos"]) and eq(di, g[name + "_di"])
+        o = geo.step(g[name + "_pos"][::4])
+        rows = g[name + "_rows"]
+        assert eq(o["latitude"], rows[:, 0]) and eq(o["longitude"], rows[:, 1])
+        assert eq(o["altitude"], rows[:, 2]) and eq(o["elevation"], rows[:, 3:5])
+        assert eq(o["step"], rows[:, 5]) and eq(o["index"], rows[:, 6:8].astype(np.int32))
+        t = geo.trace(g[name + "_pos"], g[name + "_dir"])
+        _check_trace(t, g, name + "_t")
