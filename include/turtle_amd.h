@@ -54,7 +54,7 @@ enum turtle_return {
         N_TURTLE_RETURNS
 };
 
-struct turtle_projection; /* opaque; projected maps are not on this path yet */
+struct turtle_projection;
 struct turtle_map;
 struct turtle_stack;
 struct turtle_client;
@@ -93,9 +93,28 @@ TURTLE_API void turtle_ecef_from_horizontal(double latitude, double longitude,
 TURTLE_API void turtle_ecef_to_horizontal(double latitude, double longitude,
     const double direction[3], double * azimuth, double * elevation);
 
+/* ---- projections [ref include/turtle.h:235-333; impl projection.c:53-468] ----
+ * Names as in the reference: "Lambert I|II|IIe|III|IV|93", "UTM <zone>N|S",
+ * "UTM <central meridian>.<fraction>N|S". */
+TURTLE_API enum turtle_return turtle_projection_create(
+    struct turtle_projection ** projection, const char * name);
+TURTLE_API void turtle_projection_destroy(
+    struct turtle_projection ** projection);
+TURTLE_API enum turtle_return turtle_projection_configure(
+    struct turtle_projection * projection, const char * name);
+TURTLE_API const char * turtle_projection_name(
+    const struct turtle_projection * projection);
+TURTLE_API enum turtle_return turtle_projection_project(
+    const struct turtle_projection * projection, double latitude,
+    double longitude, double * x, double * y);
+TURTLE_API enum turtle_return turtle_projection_unproject(
+    const struct turtle_projection * projection, double x, double y,
+    double * latitude, double * longitude);
+
 /* ---- maps [ref include/turtle.h:362-543; impl map.c:54-421] ----
- * `projection` must be NULL (geodetic grid): projected maps are the next row
- * of the scope table and return TURTLE_RETURN_BAD_PROJECTION for now.
+ * `projection` is NULL for a geodetic grid (x = longitude, y = latitude) or a
+ * projection name; under a stepper a projected map is looked up at the
+ * projected coordinates [impl stepper.c:65-83, :243-248].
  * turtle_map_load reads .hgt tiles [impl io/hgt.c:45-151]; other extensions
  * return TURTLE_RETURN_BAD_EXTENSION. */
 TURTLE_API enum turtle_return turtle_map_create(struct turtle_map ** map,
@@ -254,6 +273,15 @@ TURTLE_API enum turtle_return turtle_ecef_to_horizontal_n(long n,
     const double * latitude, const double * longitude,
     const double * direction /* [n][3] */, double * azimuth,
     double * elevation, int space);
+
+/* n projections / inverse projections */
+TURTLE_API enum turtle_return turtle_projection_project_n(
+    const struct turtle_projection * projection, long n,
+    const double * latitude, const double * longitude, double * x, double * y,
+    int space);
+TURTLE_API enum turtle_return turtle_projection_unproject_n(
+    const struct turtle_projection * projection, long n, const double * x,
+    const double * y, double * latitude, double * longitude, int space);
 
 /* n bilinear lookups.  `inside` is mandatory (a point outside the data is
  * reported there, never raised). */

@@ -494,3 +494,49 @@ def test_gradient_bit_exact(golden, tmp_path):
     assert np.array_equal(sin, g["sinside"])
     assert np.array_equal(glat, g["glat"]) and np.array_equal(glon, g["glon"])
     stack.destroy()
+
+
+def test_projections(golden):
+    """turtle_projection_project/unproject [ref projection.c:192-448]: OCML's
+    log/tan/pow/exp/sinh/atanh against glibc's, a few ulp of 1e7 m."""
+    g = golden("projection")
+    for k, name in enumerate(g["names"]):
+        p = TA.Projection(str(name))
+        x, y = p.project(g[f"p{k}_lat"], g[f"p{k}_lon"])
+        assert np.abs(x - g[f"p{k}_x"]).max() < 2e-8 and np.abs(y - g[f"p{k}_y"]).max() < 2e-8, name
+        la, lo = p.unproject(g[f"p{k}_x"], g[f"p{k}_y"])
+        assert np.abs(la - g[f"p{k}_ulat"]).max() < 1e-12, name
+        assert np.abs(lo - g[f"p{k}_ulon"]).max() < 1e-12, name
+        xs, ys = p.project_scalar(float(g[f"p{k}_lat"][0]), float(g[f"p{k}_lon"][0]))
+        assert xs == x[0] and ys == y[0]  # the scalar drop-in is the n = 1 batch
+        p.destroy()
+
+
+@pytest.mark.parametrize("name", ["nogeoid", "geoid"])
+def test_projected_map_under_the_stepper(golden, name, math):
+    """A UTM map + a flat sea under one layer [ref stepper.c:65-83, :243-248]."""
+    g = golden("projection")
+    m = TA.Map.create(g["nodes"], (495000.0, 497000.0), (5066000.0, 5068000.0), (0.0, 1000.0),
+                      projection="UTM 31N")
+    geoid = B.geoid_map(g["geoid_nodes"]) if name == "geoid" else None
+    st = TA.Stepper()
+    if geoid is not None:
+        st.geoid_set(geoid)
+    st.add_flat(-5.0)
+    st.add_map(m, 0.0)
+    pos, di = st.position(g[name + "_lat"], g[name + "_lon"], 150.0)
+    assert np.array_equal(di, g[name + "_di"]) and np.abs(pos - g[name + "_pos"]).max() < 5e-8
+    o = st.step(g[name + "_pos"][::4].copy(), None)
+    rows = g[name + "_rows"]
+    assert np.array_equal(o["index"], rows[:, 6:8].astype(np.int32))
+    assert np.abs(o["altitude"] - rows[:, 2]).max() < 5e-9
+    big = np.abs(rows[:, 3:5]) > 1e300
+    assert np.abs(o["elevation"][~big] - rows[:, 3:5][~big]).max() < 1e-7
+    assert np.abs(o["step"] - rows[:, 5]).max() < 1e-7
+    t = st.trace(g[name + "_pos"].copy(), g[name + "_dir"])
+    check_trace(t, g[name + "_t_index"], g[name + "_t_length"], g[name + "_t_n_steps"],
+                f"UTM map ({name})")
+    st.destroy()
+    m.destroy()
+    if geoid is not None:
+        geoid.destroy()

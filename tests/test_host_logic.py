@@ -200,3 +200,28 @@ def test_stepper_layer_rules():
     assert not _layer_exists(st, -1)
     st.destroy()
     m.destroy()
+
+
+def test_projection_names():
+    """The name parser [ref projection.c:98-171], quirks included."""
+    for name in ("Lambert I", "Lambert II", "Lambert IIe", "Lambert III", "Lambert IV",
+                 "Lambert 93", "UTM 31N", "UTM 3.5N", "UTM 19S", "  UTM 31N"):
+        p = TA.Projection(name)
+        assert p.name == name
+        p.destroy()
+    for bad, text in (("", "missing projection specifier"), ("Mercator", "invalid projection"),
+                      ("UTM", "invalid UTM specifier"), ("UTM 31X", "invalid UTM hemisphere"),
+                      ("Lambert V", "invalid projection"), ("UTM 3.5", "invalid extended UTM")):
+        with pytest.raises(TA.TurtleError) as e:
+            TA.Projection(bad)
+        assert e.value.name == "BAD_PROJECTION" and text in str(e.value), bad
+    m = TA.Map.create(shape=(3, 3), x=(0, 10), y=(0, 10), z=(0, 1), projection="Lambert 93")
+    assert m.meta()["projection"] == "Lambert 93"
+    assert TA.lib().turtle_map_projection(m.h) != 0
+    m.destroy()
+    m = TA.Map.create(shape=(3, 3))
+    assert m.meta()["projection"] is None and not TA.lib().turtle_map_projection(m.h)
+    m.destroy()
+    with pytest.raises(TA.TurtleError) as e:
+        TA.Map.create(shape=(3, 3), projection="nowhere")
+    assert e.value.name == "BAD_PROJECTION"

@@ -236,6 +236,50 @@ def scalar_ecef_from_geodetic(latitude, longitude, elevation):
     return np.array(out[:])
 
 
+# ---- projections ---------------------------------------------------------------
+
+class Projection:
+    """struct turtle_projection handle ("Lambert 93", "UTM 31N", ...)."""
+
+    def __init__(self, name):
+        self.h = C.c_void_p()
+        _check(lib().turtle_projection_create(C.byref(self.h), name.encode()))
+
+    @property
+    def name(self):
+        f = lib().turtle_projection_name
+        f.restype = C.c_char_p
+        v = f(self.h)
+        return None if v is None else v.decode()
+
+    def project(self, latitude, longitude):
+        sp = _space_of(latitude, longitude)
+        la, lo = _as(latitude, sp), _as(longitude, sp)
+        x, y = _new((la.shape[0],), sp, like=la), _new((la.shape[0],), sp, like=la)
+        _check(lib().turtle_projection_project_n(self.h, C.c_long(la.shape[0]), _ptr(la),
+                                                 _ptr(lo), _ptr(x), _ptr(y), sp))
+        return x, y
+
+    def unproject(self, x, y):
+        sp = _space_of(x, y)
+        x, y = _as(x, sp), _as(y, sp)
+        la, lo = _new((x.shape[0],), sp, like=x), _new((x.shape[0],), sp, like=x)
+        _check(lib().turtle_projection_unproject_n(self.h, C.c_long(x.shape[0]), _ptr(x),
+                                                   _ptr(y), _ptr(la), _ptr(lo), sp))
+        return la, lo
+
+    def project_scalar(self, latitude, longitude):
+        x, y = C.c_double(-1.0), C.c_double(-1.0)
+        _check(lib().turtle_projection_project(self.h, C.c_double(latitude),
+                                               C.c_double(longitude), C.byref(x), C.byref(y)))
+        return x.value, y.value
+
+    def destroy(self):
+        if self.h:
+            lib().turtle_projection_destroy(C.byref(self.h))
+        self.h = None
+
+
 # ---- maps / stacks -----------------------------------------------------------
 
 class Map:
@@ -246,13 +290,15 @@ class Map:
         self._owner = owner
 
     @classmethod
-    def create(cls, nodes_s2n=None, x=(0, 1), y=(0, 1), z=(0, 1), shape=None):
+    def create(cls, nodes_s2n=None, x=(0, 1), y=(0, 1), z=(0, 1), shape=None,
+               projection=None):
         """turtle_map_create (+ turtle_map_fill of every node if nodes given)."""
         ny, nx = nodes_s2n.shape if nodes_s2n is not None else shape
         info = _MapInfo(nx, ny, (C.c_double * 2)(*x), (C.c_double * 2)(*y),
                         (C.c_double * 2)(*z), None)
         h = C.c_void_p()
-        _check(lib().turtle_map_create(C.byref(h), C.byref(info), None))
+        _check(lib().turtle_map_create(C.byref(h), C.byref(info),
+                                       projection.encode() if projection else None))
         m = cls(h)
         if nodes_s2n is not None:
             fill = lib().turtle_map_fill
@@ -284,7 +330,7 @@ class Map:
         lib().turtle_map_meta(self.h, C.byref(info), C.byref(proj))
         return dict(nx=info.nx, ny=info.ny, x=tuple(info.x), y=tuple(info.y),
                     z=tuple(info.z), encoding=info.encoding.decode(),
-                    projection=proj.value)
+                    projection=None if proj.value is None else proj.value.decode())
 
     def elevation(self, x, y):
         """Batch bilinear lookup -> (z, inside)."""

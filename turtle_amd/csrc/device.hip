@@ -358,6 +358,112 @@ __device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
         }
 }
 
+/* ---- map projections ------------------------------------------------------ */
+
+/* [ref projection.c:329-349]: e, n, c, lambda_c, xs, ys of Lambert I, II, IIe,
+ * III, IV (NTG_71) and Lambert 93 (RGF93) */
+__constant__ double kLambert[6][6] = {
+        { 0.08248325676, 0.7604059656, 11603796.98, 0.04079234433, 600000.0, 5657616.674 },
+        { 0.08248325676, 0.7289686274, 11745793.39, 0.04079234433, 600000.0, 6199695.768 },
+        { 0.08248325676, 0.7289686274, 11745793.39, 0.04079234433, 600000.0, 8199695.768 },
+        { 0.08248325676, 0.6959127966, 11947992.52, 0.04079234433, 600000.0, 6791905.085 },
+        { 0.08248325676, 0.6712679322, 12136281.99, 0.04079234433, 234.358, 7239161.542 },
+        { 0.08181919112, 0.7253743710, 11755528.70, 0.05235987756, 700000.0, 12657560.145 }
+};
+
+/* [ref projection.c:192-210, :238-244, :286-295 (Lambert), :377-408 (UTM)] */
+__device__ __noinline__ void d_project(
+    const tamd_proj & pr, double latitude, double longitude, double & x, double & y)
+{
+        if (pr.type == TAMD_PROJ_LAMBERT) {
+                const double * P = kLambert[pr.lambert_tag];
+                const double e = P[0];
+                const double phi = latitude * kPi / 180.;
+                const double s = sin(phi);
+                const double L = log(tan(0.25 * kPi + 0.5 * phi) *
+                    pow((1. - e * s) / (1. + e * s), 0.5 * e));
+                const double cenL = P[2] * exp(-P[1] * L);
+                const double lambda = longitude / 180. * kPi;
+                const double theta = P[1] * (lambda - P[3]);
+                x = P[4] + cenL * sin(theta);
+                y = P[5] - cenL * cos(theta);
+                return;
+        }
+        const double a = 6378.137E+03;
+        const double f = 1. / 298.257223563;
+        const double E0 = 5E+05;
+        const double N0 = (pr.hemisphere > 0) ? 0. : 1E+07;
+        const double k0 = 0.9996;
+        const double n = f / (2. - f);
+        const double A = a / (1. + n) * (1. + n * n * (0.25 + 0.0625 * n * n));
+        const double alpha[3] = { n * (0.5 + n * (-2. / 3. + 5. / 16. * n)),
+                n * n * (13. / 48. - 3. / 5. * n), 61. / 240. * n * n * n };
+        const double c = 2. * sqrt(n) / (1. + n);
+        const double s = sin(latitude * kPi / 180.);
+        const double t = sinh(atanh(s) - c * atanh(c * s));
+        const double dl = (longitude - pr.longitude_0) * kPi / 180.;
+        const double zeta = atan2(t, cos(dl));
+        const double eta = atanh(sin(dl) / sqrt(1. + t * t));
+        double xs = 0., ys = 0.;
+        for (int i = 0; i < 3; i++) {
+                xs += alpha[i] * cos(2. * (i + 1) * zeta) * sinh(2. * (i + 1) * eta);
+                ys += alpha[i] * sin(2. * (i + 1) * zeta) * cosh(2. * (i + 1) * eta);
+        }
+        x = E0 + k0 * A * (eta + xs);
+        y = N0 + k0 * A * (zeta + ys);
+}
+
+/* [ref projection.c:213-230, :253-268, :304-318 (Lambert), :417-448 (UTM)] */
+__device__ __noinline__ void d_unproject(
+    const tamd_proj & pr, double x, double y, double & latitude, double & longitude)
+{
+        if (pr.type == TAMD_PROJ_LAMBERT) {
+                const double * P = kLambert[pr.lambert_tag];
+                const double e = P[0];
+                const double dx = x - P[4];
+                const double dy = y - P[5];
+                const double R = sqrt(dx * dx + dy * dy);
+                const double gamma = atan2(dx, -dy);
+                longitude = (P[3] + gamma / P[1]) * 180. / kPi;
+                const double L = -log(R / P[2]) / P[1];
+                const double eL = exp(L);
+                double phi0 = 2. * atan(eL) - 0.5 * kPi;
+                for (int it = 0; it < 64; it++) { /* converges in 3-4 rounds */
+                        const double s = sin(phi0);
+                        const double phi1 =
+                            2. * atan(pow((1. + e * s) / (1. - e * s), 0.5 * e) * eL) - 0.5 * kPi;
+                        const bool stop = fabs(phi1 - phi0) <= (double)FLT_EPSILON;
+                        phi0 = phi1;
+                        if (stop) break;
+                }
+                latitude = phi0 / kPi * 180.;
+                return;
+        }
+        const double a = 6378.137E+03;
+        const double f = 1. / 298.257223563;
+        const double E0 = 5E+05;
+        const double N0 = (pr.hemisphere > 0) ? 0. : 1E+07;
+        const double k0 = 0.9996;
+        const double n = f / (2. - f);
+        const double A = a / (1. + n) * (1. + n * n * (0.25 + 0.0625 * n * n));
+        const double beta[3] = { n * (0.5 + n * (-2. / 3. + 37. / 96. * n)),
+                n * n * (1. / 48. + 1. / 15. * n), 17. / 480. * n * n * n };
+        const double delta[3] = { n * (2. + n * (-2. / 3. - 2. * n)),
+                n * n * (7. / 3. - 8. / 5. * n), 56. / 15. * n * n * n };
+        const double zeta0 = (y - N0) / (k0 * A);
+        const double eta0 = (x - E0) / (k0 * A);
+        double zeta = zeta0, eta = eta0;
+        for (int i = 0; i < 3; i++) {
+                zeta -= beta[i] * sin(2. * (i + 1) * zeta0) * cosh(2. * (i + 1) * eta0);
+                eta -= beta[i] * cos(2. * (i + 1) * zeta0) * sinh(2. * (i + 1) * eta0);
+        }
+        const double chi = asin(sin(zeta) / cosh(eta));
+        double s = 0.;
+        for (int i = 0; i < 3; i++) s += delta[i] * sin(2. * (i + 1) * chi);
+        latitude = (chi + s) * 180. / kPi;
+        longitude = pr.longitude_0 + atan2(sinh(eta), cos(zeta)) * 180. / kPi;
+}
+
 /* ---- one grid --------------------------------------------------------- */
 
 __device__ __forceinline__ double d_node(const tamd_grid & g, int ix, int iy)
@@ -691,8 +797,15 @@ __device__ __forceinline__ bool d_source_elevation(const tamd_view & v,
         if (mt.kind == TAMD_FLAT) { /* [ref stepper.c:252-264] */
                 z = 0.;
                 return true;
-        } else if (mt.kind == TAMD_MAP) { /* [ref stepper.c:240-241] x=lon, y=lat */
-                return d_grid_elevation<FAST>(v.grids[mt.src], longitude, latitude, z);
+        } else if (mt.kind == TAMD_MAP) {
+                const tamd_grid & g = v.grids[mt.src];
+                if (g.proj.type >= 0) { /* [ref stepper.c:243-248, :304-311] */
+                        double x, y;
+                        d_project(g.proj, latitude, longitude, x, y);
+                        return d_grid_elevation<FAST>(g, x, y, z);
+                }
+                /* [ref stepper.c:240-241] geodetic grid: x = lon, y = lat */
+                return d_grid_elevation<FAST>(g, longitude, latitude, z);
         }
         return d_stack_elevation<FAST>(v, v.stacks[mt.src], latitude, longitude, z);
 }
@@ -880,6 +993,20 @@ __global__ void k_ecef_to_horizontal(long n, const double * __restrict__ lat,
                         el[r] = (arg > 1.) ? 90. :
                                              ((arg < -1.) ? -90. : asin(arg) * 180. / kPi);
                 }
+        }
+}
+
+__global__ void k_project(tamd_proj pr, int inverse, long n, const double * __restrict__ a,
+    const double * __restrict__ b, double * __restrict__ c, double * __restrict__ d)
+{
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
+             r += (long)gridDim.x * blockDim.x) {
+                double u, w;
+                if (inverse)
+                        d_unproject(pr, a[r], b[r], u, w);
+                else
+                        d_project(pr, a[r], b[r], u, w);
+                c[r] = u, d[r] = w;
         }
 }
 
@@ -1729,6 +1856,17 @@ extern "C" int tamd_k_elevation(struct tamd_view view, long n, const double * a,
         hipLaunchKernelGGL(k_elevation, dim3(grid_for(n, 256)), dim3(256), 0, g_stream,
             view, n, a, b, z, inside);
         LAUNCH_CHECK("k_elevation");
+        return 0;
+}
+
+extern "C" int tamd_k_project(struct tamd_proj proj, int inverse, long n, const double * a,
+    const double * b, double * c, double * d)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        hipLaunchKernelGGL(k_project, dim3(grid_for(n, 256)), dim3(256), 0, g_stream, proj,
+            inverse, n, a, b, c, d);
+        LAUNCH_CHECK("k_project");
         return 0;
 }
 

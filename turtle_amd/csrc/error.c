@@ -77,6 +77,14 @@ const char * turtle_error_function(turtle_function_t * caller)
         NAME(turtle_map_meta);
         NAME(turtle_map_node);
         NAME(turtle_map_projection);
+        NAME(turtle_projection_configure);
+        NAME(turtle_projection_create);
+        NAME(turtle_projection_destroy);
+        NAME(turtle_projection_name);
+        NAME(turtle_projection_project);
+        NAME(turtle_projection_unproject);
+        NAME(turtle_projection_project_n);
+        NAME(turtle_projection_unproject_n);
         NAME(turtle_stack_clear);
         NAME(turtle_stack_create);
         NAME(turtle_stack_destroy);

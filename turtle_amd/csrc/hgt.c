@@ -50,6 +50,7 @@ int tamd_hgt_probe(const char * path, struct turtle_map * m)
         m->dx = 1. / (nodes - 1), m->dy = 1. / (nodes - 1);
         m->z0 = -32767., m->dz = 1.;
         m->is_signed = 1;
+        m->projection.type = TAMD_PROJ_NONE;
         strcpy(m->encoding, "none");
         return TURTLE_RETURN_SUCCESS;
 }

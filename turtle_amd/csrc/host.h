@@ -27,6 +27,18 @@ enum turtle_return tamd_raise_(struct tamd_error * error, enum turtle_return rc,
 #define TAMD_RAISE_DEVICE()                                                    \
         TAMD_RAISE(TURTLE_RETURN_LIBRARY_ERROR, "device error: %s", tamd_dev_error())
 
+/* ---- projections [ref src/turtle/projection.h:38-46] ---------------------- */
+struct turtle_projection {
+        int type; /* enum tamd_proj_type */
+        int lambert_tag;
+        double longitude_0;
+        int hemisphere;
+        char tag[64];
+};
+int tamd_projection_configure(struct turtle_projection * projection, const char * name,
+    char * message, size_t size);
+void tamd_projection_desc(const struct turtle_projection * projection, struct tamd_proj * desc);
+
 /* ---- maps ---------------------------------------------------------------- */
 struct turtle_map {
         /* meta data [ref src/turtle/map.h:41-56] */
@@ -35,6 +47,7 @@ struct turtle_map {
         double dx, dy, dz;
         char encoding[8];
         int is_signed;        /* int16 codecs (hgt): z = (int16)v */
+        struct turtle_projection projection; /* type < 0: geodetic */
         struct turtle_stack * stack; /* owner, or NULL */
 
         uint16_t * nodes;     /* host copy: native endian, rows south->north */

@@ -32,6 +32,17 @@ extern "C" {
  * io/hgt.c:127-131, map.c:41-44]; integers are exact, so parity is
  * unaffected.  z = z0 + v * dz with v read as int16 if is_signed else uint16
  * (signed codecs use z0 = 0, dz = 1, which reproduces "(int16)v" exactly). */
+/* A map projection [ref src/turtle/projection.h:29-46]; type < 0: geodetic */
+enum tamd_proj_type { TAMD_PROJ_NONE = -1, TAMD_PROJ_LAMBERT = 0, TAMD_PROJ_UTM = 1 };
+
+struct tamd_proj {
+        int type;           /* enum tamd_proj_type */
+        int lambert_tag;    /* 0..5: I, II, IIe, III, IV, 93 */
+        double longitude_0; /* UTM central meridian, degrees */
+        int hemisphere;     /* UTM: +1 north, -1 south */
+        int pad_;
+};
+
 struct tamd_grid {
         const uint16_t * nodes;
         int nx, ny;
@@ -40,6 +51,8 @@ struct tamd_grid {
         double inv_dx, inv_dy; /* 1/dx, 1/dy: the fast-math kernels multiply */
         int is_signed;
         int pad_;
+        struct tamd_proj proj; /* x, y of a projected map; the stepper projects
+                                * (latitude, longitude) first [ref stepper.c:243-248] */
 };
 
 /* Tile directory of a stack [ref src/turtle/stack.h:32-49]: O(1) lookup
@@ -159,6 +172,9 @@ int tamd_k_philox(long n, unsigned long long seed, unsigned long long stream,
     long first, unsigned * out);
 int tamd_k_isotropic(long n, unsigned long long seed, unsigned long long stream,
     long first, double * dir);
+/* forward (inverse == 0: lat, lon -> x, y) or inverse projection of n points */
+int tamd_k_project(struct tamd_proj proj, int inverse, long n, const double * a,
+    const double * b, double * c, double * d);
 int tamd_k_tally(long n, const int * index, const double * length,
     int n_media, unsigned long long * hits, int n_bins, double length_max,
     unsigned long long * histogram);

@@ -20,9 +20,11 @@ enum turtle_return turtle_map_create(struct turtle_map ** map,
         if ((info->nx <= 0) || (info->ny <= 0) || (info->z[0] == info->z[1]))
                 return TAMD_RAISE(
                     TURTLE_RETURN_DOMAIN_ERROR, "invalid input parameter(s)");
-        if (projection != NULL)
-                return TAMD_RAISE(TURTLE_RETURN_BAD_PROJECTION,
-                    "projected maps are not supported yet (`%s')", projection);
+        struct turtle_projection proj;
+        char message[256];
+        const int prc = tamd_projection_configure(&proj, projection, message, sizeof(message));
+        if (prc != TURTLE_RETURN_SUCCESS)
+                return TAMD_RAISE((enum turtle_return)prc, "%s", message);
 
         struct turtle_map * m = calloc(1, sizeof(*m));
         if (m != NULL) m->nodes = calloc((size_t)info->nx * info->ny, sizeof(*m->nodes));
@@ -40,6 +42,7 @@ enum turtle_return turtle_map_create(struct turtle_map ** map,
         m->dy = (info->ny > 1) ? (info->y[1] - info->y[0]) / (info->ny - 1) : 0.;
         m->dz = (info->z[1] - info->z[0]) / 65535;
         strcpy(m->encoding, "none");
+        m->projection = proj;
         m->d_stale = 1;
         *map = m;
         return TURTLE_RETURN_SUCCESS;
@@ -172,11 +175,11 @@ enum turtle_return turtle_map_node(const struct turtle_map * map, int ix, int iy
         return TURTLE_RETURN_SUCCESS;
 }
 
-/* [ref map.c:394-400]: no projected maps yet, so always NULL */
+/* [ref map.c:394-400] */
 const struct turtle_projection * turtle_map_projection(const struct turtle_map * map)
 {
-        (void)map;
-        return NULL;
+        if ((map == NULL) || (map->projection.type < 0)) return NULL;
+        return &map->projection;
 }
 
 /* [ref map.c:403-421] */
@@ -194,7 +197,7 @@ void turtle_map_meta(const struct turtle_map * map, struct turtle_map_info * inf
                 info->z[1] = map->z0 + 65535 * map->dz;
                 info->encoding = map->encoding;
         }
-        if (projection != NULL) *projection = NULL;
+        if (projection != NULL) *projection = turtle_projection_name(&map->projection);
 }
 
 int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
@@ -219,6 +222,7 @@ int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
                 grid->dz = map->is_signed ? 1. : map->dz;
                 grid->is_signed = map->is_signed;
                 grid->pad_ = 0;
+                tamd_projection_desc(&map->projection, &grid->proj);
         }
         return 0;
 }

@@ -389,7 +389,9 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
                 s->view.geoid = geoid;
                 s->view.mode = TAMD_MODE_GENERIC;
                 if ((s->n_layers == 1) && (n_metas == 1) && (geoid < 0)) {
-                        if (h_metas[0].kind == TAMD_MAP) s->view.mode = TAMD_MODE_ONE_MAP;
+                        if ((h_metas[0].kind == TAMD_MAP) &&
+                            (h_grids[h_metas[0].src].proj.type < 0))
+                                s->view.mode = TAMD_MODE_ONE_MAP;
                         if (h_metas[0].kind == TAMD_STACK) s->view.mode = TAMD_MODE_ONE_STACK;
                 }
                 s->epoch = tamd_geometry_epoch;
