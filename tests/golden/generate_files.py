@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""G10: data files written BY the reference (turtle_map_dump) for the ingest
+tests, plus what the reference reads back from them.
+
+The reference dlopen()s "libtiff.so"/"libpng.so", which exist here only under
+their versioned names: this script re-executes itself with a private directory
+of symlinks on LD_LIBRARY_PATH (build container only).
+
+  geotiff_utm.tif   201x201 int16 GeoTIFF, UTM-ish frame     -> geotiff.npz
+"""
+import glob
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def reexec_with_links():
+    d = tempfile.mkdtemp(prefix="turtle_links_")
+    for stem in ("libtiff", "libpng"):
+        hits = sorted(glob.glob(f"/usr/lib/x86_64-linux-gnu/{stem}*.so.*"))
+        if hits:
+            os.symlink(hits[0], os.path.join(d, stem + ".so"))
+    env = dict(os.environ, LD_LIBRARY_PATH=d + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
+               TURTLE_LINKS_READY="1")
+    sys.exit(subprocess.call([sys.executable, os.path.abspath(__file__)], env=env))
+
+
+def main():
+    import ctypes as C
+    from oracle import ref_ffi as R
+    L = R.lib()
+    rng = np.random.Generator(np.random.Philox(1010))
+    i = np.arange(201, dtype=np.float64)
+    nodes = np.rint(400.0 + 300.0 * np.sin(i / 13.0)[None, :] * np.cos(i / 29.0)[:, None]
+                    - 2.0 * i[:, None])
+    # a map whose 16-bit codes ARE the elevations (z0 = -32767, dz = 1), as a
+    # GeoTIFF stores them [ref io/geotiff16.c:186-187, :230-238]
+    m = R.RefMap.create(nodes, (495000.0, 497000.0), (5066000.0, 5068000.0),
+                        (-32767.0, 32768.0))
+    path = os.path.join(OUT, "geotiff_utm.tif")
+    rc = L.turtle_map_dump(m.h, path.encode())
+    assert rc == 0, R.errors()
+    m.destroy()
+    back = R.RefMap.load(path)
+    info = R.MapInfo()
+    L.turtle_map_meta(back.h, C.byref(info), None)
+    ix = rng.integers(0, 201, 300)
+    iy = rng.integers(0, 201, 300)
+    node = np.array([back.node(int(a), int(b)) for a, b in zip(ix, iy)])
+    qx = rng.uniform(494990.0, 497010.0, 1000)
+    qy = rng.uniform(5065990.0, 5068010.0, 1000)
+    qz, qin = back.elevation(qx, qy)
+    back.destroy()
+    np.savez_compressed(os.path.join(OUT, "geotiff.npz"), nodes=nodes, nx=info.nx, ny=info.ny,
+                        x=np.array(info.x[:]), y=np.array(info.y[:]), z=np.array(info.z[:]),
+                        ix=ix, iy=iy, node=node, qx=qx, qy=qy, qz=qz, qin=qin)
+    print("geotiff_utm.tif", os.path.getsize(path), "bytes; meta", info.nx, info.ny, info.x[:],
+          info.y[:], info.z[:], "errors:", R.errors())
+
+
+if __name__ == "__main__":
+    if os.environ.get("TURTLE_LINKS_READY") != "1":
+        reexec_with_links()
+    main()

@@ -540,3 +540,16 @@ def test_projected_map_under_the_stepper(golden, name, math):
     m.destroy()
     if geoid is not None:
         geoid.destroy()
+
+
+def test_geotiff_map_elevation(golden):
+    """A GeoTIFF written by the reference, read natively, looked up on the GPU:
+    bit-exact against what the reference computed from the same file."""
+    import os
+    g = golden("geotiff")
+    m = TA.Map.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                 "geotiff_utm.tif"))
+    z, inside = m.elevation(g["qx"], g["qy"])
+    assert np.array_equal(inside, g["qin"])
+    assert np.array_equal(z[inside == 1], g["qz"][inside == 1])
+    m.destroy()

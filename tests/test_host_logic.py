@@ -225,3 +225,80 @@ def test_projection_names():
     with pytest.raises(TA.TurtleError) as e:
         TA.Map.create(shape=(3, 3), projection="nowhere")
     assert e.value.name == "BAD_PROJECTION"
+
+
+def _write_tiff(path, nodes_n2s, byteorder, x0, y_top, dx, dy, compression=1, rows_per_strip=None):
+    """A minimal GeoTIFF-16 writer for the ingest tests (baseline TIFF, strips)."""
+    import struct
+    e = "<" if byteorder == "II" else ">"
+    ny, nx = nodes_n2s.shape
+    rps = rows_per_strip or ny
+    n_strips = (ny + rps - 1) // rps
+    data = nodes_n2s.astype(e + "i2").tobytes()
+    entries = []
+    blob = b""
+    base = 8 + len(data)
+
+    def extra(payload):
+        nonlocal blob
+        off = base + len(blob)
+        blob += payload
+        return off
+
+    offs = [8 + 2 * nx * rps * k for k in range(n_strips)]
+    cnts = [2 * nx * min(rps, ny - rps * k) for k in range(n_strips)]
+    entries += [(256, 4, 1, nx), (257, 4, 1, ny), (258, 3, 1, 16), (259, 3, 1, compression),
+                (262, 3, 1, 1), (277, 3, 1, 1), (278, 4, 1, rps)]
+    if n_strips == 1:
+        entries += [(273, 4, 1, offs[0]), (279, 4, 1, cnts[0])]
+    else:
+        entries += [(273, 4, n_strips, extra(struct.pack(e + f"{n_strips}I", *offs))),
+                    (279, 4, n_strips, extra(struct.pack(e + f"{n_strips}I", *cnts)))]
+    entries += [(33550, 12, 3, extra(struct.pack(e + "3d", dx, dy, 0.0))),
+                (33922, 12, 6, extra(struct.pack(e + "6d", 0, 0, 0, x0, y_top, 0)))]
+    entries.sort()
+    ifd_at = base + len(blob)
+    ifd = struct.pack(e + "H", len(entries))
+    for tag, typ, cnt, val in entries:
+        if typ == 3:
+            ifd += struct.pack(e + "HHIHH", tag, typ, cnt, val, 0)
+        else:
+            ifd += struct.pack(e + "HHII", tag, typ, cnt, val)
+    ifd += struct.pack(e + "I", 0)
+    with open(path, "wb") as f:
+        f.write(byteorder.encode() + struct.pack(e + "HI", 42, ifd_at) + data + blob + ifd)
+
+
+def test_geotiff_ingest(tmp_path):
+    """Native GeoTIFF-16 reader against a file WRITTEN BY THE REFERENCE
+    (tests/golden/geotiff_utm.tif, see generate_files.py) and what the reference
+    read back from it [ref io/geotiff16.c:165-258]; plus big-endian, multi-strip
+    and refused layouts from a writer of our own."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = dict(np.load(os.path.join(here, "golden", "geotiff.npz")))
+    m = TA.Map.load(os.path.join(here, "golden", "geotiff_utm.tif"))
+    meta = m.meta()
+    assert (meta["nx"], meta["ny"]) == (int(g["nx"]), int(g["ny"]))
+    assert meta["x"] == tuple(g["x"]) and meta["y"] == tuple(g["y"]) and meta["z"] == tuple(g["z"])
+    assert meta["encoding"] == "tif" and meta["projection"] is None
+    for ix, iy, ref in zip(g["ix"], g["iy"], g["node"]):
+        assert m.node(int(ix), int(iy)) == tuple(ref)
+    m.destroy()
+    nodes = g["nodes"]  # south -> north
+    for order, rps in (("MM", None), ("II", 7), ("MM", 1)):
+        p = os.path.join(tmp_path, f"t_{order}_{rps}.tif")
+        _write_tiff(p, nodes[::-1], order, 495000.0, 5068000.0, 10.0, 10.0, rows_per_strip=rps)
+        m = TA.Map.load(p)
+        assert m.meta()["x"] == (495000.0, 497000.0) and m.meta()["y"] == (5066000.0, 5068000.0)
+        for ix, iy in ((0, 0), (200, 200), (17, 133), (133, 17)):
+            assert m.node(ix, iy)[2] == nodes[iy, ix]
+        m.destroy()
+    p = os.path.join(tmp_path, "lzw.tif")
+    _write_tiff(p, nodes[::-1], "II", 0.0, 0.0, 1.0, 1.0, compression=5)
+    with pytest.raises(TA.TurtleError) as e:
+        TA.Map.load(p)
+    assert e.value.name == "BAD_FORMAT"
+    open(os.path.join(tmp_path, "junk.tif"), "wb").write(b"not a tiff at all")
+    with pytest.raises(TA.TurtleError) as e:
+        TA.Map.load(os.path.join(tmp_path, "junk.tif"))
+    assert e.value.name == "BAD_FORMAT"

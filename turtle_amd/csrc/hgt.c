@@ -51,7 +51,7 @@ int tamd_hgt_probe(const char * path, struct turtle_map * m)
         m->z0 = -32767., m->dz = 1.;
         m->is_signed = 1;
         m->projection.type = TAMD_PROJ_NONE;
-        strcpy(m->encoding, "none");
+        strcpy(m->encoding, "hgt"); /* [ref io.c:96-97] the extension */
         return TURTLE_RETURN_SUCCESS;
 }
 

@@ -74,7 +74,24 @@ void turtle_map_destroy(struct turtle_map ** map)
         *map = NULL;
 }
 
-/* Extension dispatch [ref src/turtle/io.c:60-104]: hgt only, for now. */
+/* Extension dispatch [ref src/turtle/io.c:60-104]: hgt and (uncompressed,
+ * stripped) GeoTIFF-16; png, grd and asc are not on this path. */
+int tamd_codec_for(const char * path, int (**probe)(const char *, struct turtle_map *),
+    int (**read)(const char *, struct turtle_map *))
+{
+        const char * ext = strrchr(path, '.');
+        if (ext == NULL) return 0;
+        if (strcmp(ext + 1, "hgt") == 0) {
+                *probe = &tamd_hgt_probe, *read = &tamd_hgt_read;
+                return 1;
+        }
+        if (strcmp(ext + 1, "tif") == 0) {
+                *probe = &tamd_tiff_probe, *read = &tamd_tiff_read;
+                return 1;
+        }
+        return 0;
+}
+
 enum turtle_return tamd_map_load_(struct turtle_map ** map, const char * path,
     struct tamd_error * error, const char * file, int line)
 {
@@ -83,7 +100,9 @@ enum turtle_return tamd_map_load_(struct turtle_map ** map, const char * path,
         if (ext == NULL)
                 return tamd_raise_(error, TURTLE_RETURN_BAD_EXTENSION, file, line,
                     "missing file extension");
-        if (strcmp(ext + 1, "hgt") != 0)
+        int (*probe)(const char *, struct turtle_map *);
+        int (*read)(const char *, struct turtle_map *);
+        if (!tamd_codec_for(path, &probe, &read))
                 return tamd_raise_(error, TURTLE_RETURN_BAD_EXTENSION, file, line,
                     "unsuported file format `%s'", ext + 1);
 
@@ -91,11 +110,10 @@ enum turtle_return tamd_map_load_(struct turtle_map ** map, const char * path,
         if (m == NULL)
                 return tamd_raise_(error, TURTLE_RETURN_MEMORY_ERROR, file, line,
                     "could not allocate memory for map `%s'", path);
-        int rc = tamd_hgt_probe(path, m);
+        int rc = probe(path, m);
         if (rc == TURTLE_RETURN_SUCCESS) {
                 m->nodes = malloc((size_t)m->nx * m->ny * sizeof(*m->nodes));
-                rc = (m->nodes == NULL) ? TURTLE_RETURN_MEMORY_ERROR :
-                                          tamd_hgt_read(path, m);
+                rc = (m->nodes == NULL) ? TURTLE_RETURN_MEMORY_ERROR : read(path, m);
         }
         if (rc != TURTLE_RETURN_SUCCESS) {
                 free(m->nodes);
@@ -106,7 +124,9 @@ enum turtle_return tamd_map_load_(struct turtle_map ** map, const char * path,
                             "could not allocate memory for map `%s'" :
                             ((rc == TURTLE_RETURN_BAD_FORMAT + 100) ?
                                     "missing data when reading file `%s'" :
-                                    "invalid hgt filename for `%s'"));
+                                    ((strcmp(ext + 1, "hgt") == 0) ?
+                                            "invalid hgt filename for `%s'" :
+                                            "not an uncompressed 16-bit strip TIFF: `%s'")));
                 if (rc == TURTLE_RETURN_BAD_FORMAT + 100) rc = TURTLE_RETURN_BAD_FORMAT;
                 return tamd_raise_(error, (enum turtle_return)rc, file, line, text, path);
         }

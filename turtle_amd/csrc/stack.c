@@ -22,8 +22,25 @@
 
 static int is_tile_file(const char * name)
 {
-        const char * ext = strrchr(name, '.');
-        return (ext != NULL) && (strcmp(ext + 1, "hgt") == 0);
+        int (*probe)(const char *, struct turtle_map *);
+        int (*read)(const char *, struct turtle_map *);
+        return tamd_codec_for(name, &probe, &read);
+}
+
+static int tile_probe(const char * path, struct turtle_map * meta)
+{
+        int (*probe)(const char *, struct turtle_map *);
+        int (*read)(const char *, struct turtle_map *);
+        if (!tamd_codec_for(path, &probe, &read)) return TURTLE_RETURN_BAD_EXTENSION;
+        return probe(path, meta);
+}
+
+static int tile_read(const char * path, struct turtle_map * map)
+{
+        int (*probe)(const char *, struct turtle_map *);
+        int (*read)(const char *, struct turtle_map *);
+        if (!tamd_codec_for(path, &probe, &read)) return TURTLE_RETURN_BAD_EXTENSION;
+        return read(path, map);
 }
 
 /* [ref stack.c:46-213] */
@@ -52,13 +69,13 @@ enum turtle_return turtle_stack_create(struct turtle_stack ** stack,
                 if ((stat(file, &sb) != 0) || S_ISDIR(sb.st_mode)) continue;
                 if (!is_tile_file(entry->d_name)) continue; /* unknown format */
                 struct turtle_map meta;
-                const int rc = tamd_hgt_probe(file, &meta);
+                const int rc = tile_probe(file, &meta);
                 if (rc != TURTLE_RETURN_SUCCESS) {
                         closedir(dir);
                         return TAMD_RAISE((enum turtle_return)rc,
                             (rc == TURTLE_RETURN_PATH_ERROR) ?
                                 "could not open file `%s'" :
-                                "invalid hgt filename for `%s'",
+                                "invalid file name or layout for `%s'",
                             file);
                 }
                 const double dx = meta.dx * (meta.nx - 1);
@@ -126,7 +143,7 @@ enum turtle_return turtle_stack_create(struct turtle_stack ** stack,
                 if ((stat(file, &sb) != 0) || S_ISDIR(sb.st_mode)) continue;
                 if (!is_tile_file(entry->d_name)) continue;
                 struct turtle_map meta;
-                if (tamd_hgt_probe(file, &meta) != TURTLE_RETURN_SUCCESS) continue;
+                if (tile_probe(file, &meta) != TURTLE_RETURN_SUCCESS) continue;
                 const int ix = (int)((meta.x0 - long_min) / long_delta);
                 const int iy = (int)((meta.y0 - lat_min) / lat_delta);
                 const size_t i = (size_t)iy * long_n + ix;
@@ -187,11 +204,11 @@ int tamd_stack_load_all(struct turtle_stack * s, char * message, size_t size)
                 if ((s->path[i] == NULL) || (s->tile[i] != NULL)) continue;
                 struct turtle_map * m = calloc(1, sizeof(*m));
                 int rc = (m == NULL) ? TURTLE_RETURN_MEMORY_ERROR :
-                                       tamd_hgt_probe(s->path[i], m);
+                                       tile_probe(s->path[i], m);
                 if (rc == TURTLE_RETURN_SUCCESS) {
                         m->nodes = malloc((size_t)m->nx * m->ny * sizeof(*m->nodes));
                         rc = (m->nodes == NULL) ? TURTLE_RETURN_MEMORY_ERROR :
-                                                  tamd_hgt_read(s->path[i], m);
+                                                  tile_read(s->path[i], m);
                 }
                 if (rc != TURTLE_RETURN_SUCCESS) {
                         if (m != NULL) free(m->nodes);
