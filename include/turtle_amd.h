@@ -117,8 +117,11 @@ TURTLE_API enum turtle_return turtle_projection_unproject(
  * projected coordinates [impl stepper.c:65-83, :243-248].
  * turtle_map_load reads .hgt tiles [impl io/hgt.c:45-151] and uncompressed,
  * stripped GeoTIFF-16 .tif files [impl io/geotiff16.c:165-258] with a native
- * reader (no libtiff); other extensions return TURTLE_RETURN_BAD_EXTENSION,
- * compressed or tiled TIFFs TURTLE_RETURN_BAD_FORMAT. */
+ * reader (no libtiff), and the reference's own .png map format (16-bit
+ * greyscale + JSON "topography" header, incl. its projection) [impl
+ * io/png16.c:183-448] with a native reader (zlib's inflate only); other
+ * extensions return TURTLE_RETURN_BAD_EXTENSION, compressed or tiled TIFFs and
+ * non-16-bit or interlaced PNGs TURTLE_RETURN_BAD_FORMAT. */
 TURTLE_API enum turtle_return turtle_map_create(struct turtle_map ** map,
     const struct turtle_map_info * info, const char * projection);
 TURTLE_API void turtle_map_destroy(struct turtle_map ** map);

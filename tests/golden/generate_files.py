@@ -7,6 +7,8 @@ their versioned names: this script re-executes itself with a private directory
 of symlinks on LD_LIBRARY_PATH (build container only).
 
   geotiff_utm.tif   201x201 int16 GeoTIFF, UTM-ish frame     -> geotiff.npz
+  map_utm.png       201x201 PNG-16 + JSON header, "UTM 31N"   -> png.npz
+                    (the reference's own map format, tests/test-turtle.c:67-95)
 """
 import glob
 import os
@@ -63,6 +65,29 @@ def main():
                         ix=ix, iy=iy, node=node, qx=qx, qy=qy, qz=qz, qin=qin)
     print("geotiff_utm.tif", os.path.getsize(path), "bytes; meta", info.nx, info.ny, info.x[:],
           info.y[:], info.z[:], "errors:", R.errors())
+
+    # ---- PNG-16 with the JSON "topography" header ----
+    nodes = 350.0 + 300.0 * np.sin(i / 11.0)[None, :] * np.cos(i / 19.0)[:, None] + 0.5 * i[:, None]
+    m = R.RefMap.create(nodes, (495000.0, 497000.0), (5066000.0, 5068000.0), (0.0, 1000.0),
+                        "UTM 31N")
+    path = os.path.join(OUT, "map_utm.png")
+    rc = L.turtle_map_dump(m.h, path.encode())
+    assert rc == 0, R.errors()
+    m.destroy()
+    back = R.RefMap.load(path)
+    info = R.MapInfo()
+    proj = C.c_char_p()
+    L.turtle_map_meta(back.h, C.byref(info), C.byref(proj))
+    projection = proj.value.decode()  # points into the map: read before destroying it
+    node = np.array([back.node(int(a), int(b)) for a, b in zip(ix, iy)])
+    qz, qin = back.elevation(qx, qy)
+    back.destroy()
+    np.savez_compressed(os.path.join(OUT, "png.npz"), nodes=nodes, nx=info.nx, ny=info.ny,
+                        x=np.array(info.x[:]), y=np.array(info.y[:]), z=np.array(info.z[:]),
+                        projection=np.array(projection), ix=ix, iy=iy, node=node,
+                        qx=qx, qy=qy, qz=qz, qin=qin)
+    print("map_utm.png", os.path.getsize(path), "bytes; meta", info.nx, info.ny, info.x[:],
+          info.y[:], info.z[:], projection, "errors:", R.errors())
 
 
 if __name__ == "__main__":

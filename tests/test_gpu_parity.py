@@ -553,3 +553,32 @@ def test_geotiff_map_elevation(golden):
     assert np.array_equal(inside, g["qin"])
     assert np.array_equal(z[inside == 1], g["qz"][inside == 1])
     m.destroy()
+
+
+def test_png_map_elevation_and_stepper(golden):
+    """The reference's own map file format, read natively: bit-exact lookups,
+    and the projected map works under a stepper (the set-up of
+    examples/example-stepper.c: flat + projected map)."""
+    import os
+    g = golden("png")
+    m = TA.Map.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                 "map_utm.png"))
+    z, inside = m.elevation(g["qx"], g["qy"])
+    assert np.array_equal(inside, g["qin"])
+    assert np.array_equal(z[inside == 1], g["qz"][inside == 1])
+    st = TA.Stepper()
+    st.add_flat(0.0)
+    st.add_map(m, 0.0)
+    p = TA.Projection("UTM 31N")
+    lat, lon = p.unproject(np.array([496000.0]), np.array([5067000.0]))
+    pos, di = st.position(lat, lon, 10.0)
+    o = st.step(pos, None)
+    assert di[0] == 0 and o["index"][0, 0] == 1
+    zc, _ = m.elevation(np.array([496000.0]), np.array([5067000.0]))
+    # the UTM series pair is only inverse to ~1 mm [ref projection.c:377-448],
+    # so the stepper looks the map up a millimetre away from (496000, 5067000)
+    assert abs(o["elevation"][0, 0] - zc[0]) < 1e-2
+    assert abs(o["altitude"][0] - o["elevation"][0, 0] - 10.0) < 1e-8
+    p.destroy()
+    st.destroy()
+    m.destroy()

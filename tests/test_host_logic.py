@@ -302,3 +302,25 @@ def test_geotiff_ingest(tmp_path):
     with pytest.raises(TA.TurtleError) as e:
         TA.Map.load(os.path.join(tmp_path, "junk.tif"))
     assert e.value.name == "BAD_FORMAT"
+
+
+def test_png_map_ingest(tmp_path):
+    """Native reader of the reference's PNG-16 map format against a file
+    WRITTEN BY THE REFERENCE (tests/golden/map_utm.png) and what the reference
+    read back from it [ref io/png16.c:183-448]: JSON header with C99 hex floats,
+    projection name, big-endian samples, north row first."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = dict(np.load(os.path.join(here, "golden", "png.npz")))
+    m = TA.Map.load(os.path.join(here, "golden", "map_utm.png"))
+    meta = m.meta()
+    assert (meta["nx"], meta["ny"]) == (int(g["nx"]), int(g["ny"]))
+    assert meta["x"] == tuple(g["x"]) and meta["y"] == tuple(g["y"]) and meta["z"] == tuple(g["z"])
+    assert meta["encoding"] == "png" and meta["projection"] == str(g["projection"]) == "UTM 31N"
+    for ix, iy, ref in zip(g["ix"], g["iy"], g["node"]):
+        assert m.node(int(ix), int(iy)) == tuple(ref)
+    m.destroy()
+    bad = os.path.join(tmp_path, "bad.png")
+    open(bad, "wb").write(b"\\x89PNG\\r\\n\\x1a\\n" + b"\\0" * 40)
+    with pytest.raises(TA.TurtleError) as e:
+        TA.Map.load(bad)
+    assert e.value.name == "BAD_FORMAT"

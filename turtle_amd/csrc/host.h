@@ -66,6 +66,8 @@ int tamd_hgt_probe(const char * path, struct turtle_map * meta);
 int tamd_hgt_read(const char * path, struct turtle_map * map);
 int tamd_tiff_probe(const char * path, struct turtle_map * meta);
 int tamd_tiff_read(const char * path, struct turtle_map * map);
+int tamd_png_probe(const char * path, struct turtle_map * meta);
+int tamd_png_read(const char * path, struct turtle_map * map);
 /* Extension dispatch [ref src/turtle/io.c:60-104]: 0 if no codec handles it */
 int tamd_codec_for(const char * path, int (**probe)(const char *, struct turtle_map *),
     int (**read)(const char *, struct turtle_map *));

@@ -74,8 +74,9 @@ void turtle_map_destroy(struct turtle_map ** map)
         *map = NULL;
 }
 
-/* Extension dispatch [ref src/turtle/io.c:60-104]: hgt and (uncompressed,
- * stripped) GeoTIFF-16; png, grd and asc are not on this path. */
+/* Extension dispatch [ref src/turtle/io.c:60-104]: hgt, (uncompressed,
+ * stripped) GeoTIFF-16 and the reference's PNG-16 map format; grd and asc
+ * (text formats, used for geoid tables) are not on this path. */
 int tamd_codec_for(const char * path, int (**probe)(const char *, struct turtle_map *),
     int (**read)(const char *, struct turtle_map *))
 {
@@ -87,6 +88,10 @@ int tamd_codec_for(const char * path, int (**probe)(const char *, struct turtle_
         }
         if (strcmp(ext + 1, "tif") == 0) {
                 *probe = &tamd_tiff_probe, *read = &tamd_tiff_read;
+                return 1;
+        }
+        if (strcmp(ext + 1, "png") == 0) {
+                *probe = &tamd_png_probe, *read = &tamd_png_read;
                 return 1;
         }
         return 0;
