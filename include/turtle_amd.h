@@ -119,7 +119,8 @@ TURTLE_API enum turtle_return turtle_projection_unproject(
  * stripped GeoTIFF-16 .tif files [impl io/geotiff16.c:165-258] with a native
  * reader (no libtiff), and the reference's own .png map format (16-bit
  * greyscale + JSON "topography" header, incl. its projection) [impl
- * io/png16.c:183-448] with a native reader (zlib's inflate only); other
+ * io/png16.c:183-448] with a native reader (zlib's inflate only), and the
+ * text formats .grd / .asc [impl io/grd.c, io/asc.c]; other
  * extensions return TURTLE_RETURN_BAD_EXTENSION, compressed or tiled TIFFs and
  * non-16-bit or interlaced PNGs TURTLE_RETURN_BAD_FORMAT. */
 TURTLE_API enum turtle_return turtle_map_create(struct turtle_map ** map,

@@ -9,6 +9,10 @@ of symlinks on LD_LIBRARY_PATH (build container only).
   geotiff_utm.tif   201x201 int16 GeoTIFF, UTM-ish frame     -> geotiff.npz
   map_utm.png       201x201 PNG-16 + JSON header, "UTM 31N"   -> png.npz
                     (the reference's own map format, tests/test-turtle.c:67-95)
+  geoid_small.grd   text grid in the EGM96 ww15mgh.grd layout  -> text.npz
+  dem_small.asc     ESRI ASCII grid with a nodata value        -> text.npz
+                    (both AUTHORED here -- the reference cannot write them --
+                    and read back by the reference)
 """
 import glob
 import os
@@ -88,6 +92,38 @@ def main():
                         qx=qx, qy=qy, qz=qz, qin=qin)
     print("map_utm.png", os.path.getsize(path), "bytes; meta", info.nx, info.ny, info.x[:],
           info.y[:], info.z[:], projection, "errors:", R.errors())
+
+    # ---- text formats: we write the files, the reference reads them ----
+    lat = np.arange(-2.0, 2.0 + 1e-9, 0.25)          # 17 rows
+    lon = np.arange(10.0, 14.0 + 1e-9, 0.5)          # 9 columns
+    und = 12.5 * np.sin(lon / 3.0)[None, :] - 7.0 * np.cos(lat * 1.3)[:, None]
+    grd = os.path.join(OUT, "geoid_small.grd")
+    with open(grd, "w") as f:
+        f.write(f"  {lat[0]:.6f}   {lat[-1]:.6f}   {lon[0]:.6f}  {lon[-1]:.6f}   0.250000   0.500000\n")
+        for row in und:                               # file order = rows iy = 0, 1, ...
+            f.write(" ".join(f"{v:9.3f}" for v in row) + "\n")
+    asc = os.path.join(OUT, "dem_small.asc")
+    dem = np.rint(800.0 + 300.0 * np.sin(np.arange(12) / 2.0)[None, :]
+                  * np.cos(np.arange(10) / 3.0)[:, None])
+    dem[2, 3] = -9999.0
+    with open(asc, "w") as f:
+        f.write("ncols 12\nnrows 10\nxllcorner 3.0\nyllcorner 45.0\ncellsize 0.01\n"
+                "NODATA_value -9999\n")
+        for row in dem:                               # north row first
+            f.write(" ".join(f"{v:.1f}" for v in row) + "\n")
+    out = {}
+    for tag, path in (("grd", grd), ("asc", asc)):
+        back = R.RefMap.load(path)
+        info = R.MapInfo()
+        L.turtle_map_meta(back.h, C.byref(info), None)
+        node = np.array([[back.node(a, b)[2] for a in range(info.nx)] for b in range(info.ny)])
+        out.update({f"{tag}_nx": info.nx, f"{tag}_ny": info.ny, f"{tag}_x": np.array(info.x[:]),
+                    f"{tag}_y": np.array(info.y[:]), f"{tag}_z": np.array(info.z[:]),
+                    f"{tag}_node": node})
+        back.destroy()
+        print(os.path.basename(path), info.nx, info.ny, info.x[:], info.y[:], info.z[:])
+    np.savez_compressed(os.path.join(OUT, "text.npz"), **out)
+    print("errors:", R.errors())
 
 
 if __name__ == "__main__":

@@ -324,3 +324,21 @@ def test_png_map_ingest(tmp_path):
     with pytest.raises(TA.TurtleError) as e:
         TA.Map.load(bad)
     assert e.value.name == "BAD_FORMAT"
+
+
+def test_text_grid_ingest():
+    """.grd and .asc readers against what the REFERENCE read from the same
+    files (tests/golden/text.npz): meta incl. the 16-bit quantisation range
+    found by the reference's own scan, and every node, bit for bit
+    [ref io/grd.c:45-157, io/asc.c:45-150]."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = dict(np.load(os.path.join(here, "golden", "text.npz")))
+    for tag, name in (("grd", "geoid_small.grd"), ("asc", "dem_small.asc")):
+        m = TA.Map.load(os.path.join(here, "golden", name))
+        meta = m.meta()
+        assert (meta["nx"], meta["ny"]) == (int(g[tag + "_nx"]), int(g[tag + "_ny"]))
+        assert meta["x"] == tuple(g[tag + "_x"]) and meta["y"] == tuple(g[tag + "_y"])
+        assert meta["z"] == tuple(g[tag + "_z"]) and meta["encoding"] == tag
+        node = np.array([[m.node(a, b)[2] for a in range(meta["nx"])] for b in range(meta["ny"])])
+        assert np.array_equal(node, g[tag + "_node"])
+        m.destroy()

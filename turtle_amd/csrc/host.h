@@ -61,13 +61,18 @@ enum turtle_return tamd_map_load_(struct turtle_map ** map, const char * path,
     struct tamd_error * error, const char * file, int line);
 /* Codecs (hgt.c, tiff.c): a header-only probe that fills the meta data, and a
  * full read into map->nodes (native endian, rows south->north).  Both return
- * an enum turtle_return; BAD_FORMAT + 100 stands for "missing data". */
+ * an enum turtle_return; BAD_FORMAT + 100 stands for "missing data", + 101 for
+ * "inconsistent data", + 102 for "could not read the header". */
 int tamd_hgt_probe(const char * path, struct turtle_map * meta);
 int tamd_hgt_read(const char * path, struct turtle_map * map);
 int tamd_tiff_probe(const char * path, struct turtle_map * meta);
 int tamd_tiff_read(const char * path, struct turtle_map * map);
 int tamd_png_probe(const char * path, struct turtle_map * meta);
 int tamd_png_read(const char * path, struct turtle_map * map);
+int tamd_grd_probe(const char * path, struct turtle_map * meta);
+int tamd_grd_read(const char * path, struct turtle_map * map);
+int tamd_asc_probe(const char * path, struct turtle_map * meta);
+int tamd_asc_read(const char * path, struct turtle_map * map);
 /* Extension dispatch [ref src/turtle/io.c:60-104]: 0 if no codec handles it */
 int tamd_codec_for(const char * path, int (**probe)(const char *, struct turtle_map *),
     int (**read)(const char *, struct turtle_map *));

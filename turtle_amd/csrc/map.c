@@ -74,9 +74,8 @@ void turtle_map_destroy(struct turtle_map ** map)
         *map = NULL;
 }
 
-/* Extension dispatch [ref src/turtle/io.c:60-104]: hgt, (uncompressed,
- * stripped) GeoTIFF-16 and the reference's PNG-16 map format; grd and asc
- * (text formats, used for geoid tables) are not on this path. */
+/* Extension dispatch [ref src/turtle/io.c:60-104]: the reference's five
+ * formats -- hgt, GeoTIFF-16 (uncompressed strips), PNG-16 maps, grd, asc. */
 int tamd_codec_for(const char * path, int (**probe)(const char *, struct turtle_map *),
     int (**read)(const char *, struct turtle_map *))
 {
@@ -92,6 +91,14 @@ int tamd_codec_for(const char * path, int (**probe)(const char *, struct turtle_
         }
         if (strcmp(ext + 1, "png") == 0) {
                 *probe = &tamd_png_probe, *read = &tamd_png_read;
+                return 1;
+        }
+        if (strcmp(ext + 1, "grd") == 0) {
+                *probe = &tamd_grd_probe, *read = &tamd_grd_read;
+                return 1;
+        }
+        if (strcmp(ext + 1, "asc") == 0) {
+                *probe = &tamd_asc_probe, *read = &tamd_asc_read;
                 return 1;
         }
         return 0;
@@ -123,6 +130,13 @@ enum turtle_return tamd_map_load_(struct turtle_map ** map, const char * path,
         if (rc != TURTLE_RETURN_SUCCESS) {
                 free(m->nodes);
                 free(m);
+                if (rc == TURTLE_RETURN_BAD_FORMAT + 101) {
+                        return tamd_raise_(error, TURTLE_RETURN_BAD_FORMAT, file, line,
+                            "inconsistent data in file `%s'", path);
+                }
+                if (rc == TURTLE_RETURN_BAD_FORMAT + 102)
+                        return tamd_raise_(error, TURTLE_RETURN_BAD_FORMAT, file, line,
+                            "could not read the header of file `%s'", path);
                 const char * text = (rc == TURTLE_RETURN_PATH_ERROR) ?
                     "could not open file `%s'" :
                     ((rc == TURTLE_RETURN_MEMORY_ERROR) ?
