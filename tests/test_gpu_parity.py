@@ -582,3 +582,20 @@ def test_png_map_elevation_and_stepper(golden):
     p.destroy()
     st.destroy()
     m.destroy()
+
+
+def test_plain_c_caller(tmp_path):
+    """examples/trace_rays.c: a C99 program against include/turtle.h, built
+    with gcc only and linked to libturtle_amd.so -- the scalar drop-in loop and
+    one trace_n call agree (the program checks; we check its exit code)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(tmp_path, "trace_rays")
+    lib = os.path.join(root, "turtle_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "trace_rays.c"), "-L" + lib,
+                           "-lturtle_amd", "-lm", "-Wl,-rpath," + lib, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(out.stdout[-600:], out.stderr[-300:])
+    assert out.returncode == 0 and "0 disagreements" in out.stdout
