@@ -38,6 +38,12 @@
 
 typedef unsigned long long ull;
 
+/* Node arrays live in HBM.  Pointers that reach a kernel inside a descriptor
+ * table are generic as far as the compiler can tell, and a generic load is a
+ * flat_load (slower, and it ties up both memory counters): say "global". */
+typedef const __attribute__((address_space(1))) uint16_t * global_nodes_t;
+#define GLOBAL_NODES(p) ((global_nodes_t)(p))
+
 /* ======================================================================== */
 /*                               device math                                */
 /* ======================================================================== */
@@ -468,7 +474,7 @@ __device__ __noinline__ void d_unproject(
 
 __device__ __forceinline__ double d_node(const tamd_grid & g, int ix, int iy)
 {
-        const uint16_t raw = g.nodes[(long)iy * g.nx + ix];
+        const uint16_t raw = GLOBAL_NODES(g.nodes)[(long)iy * g.nx + ix];
         const double v = g.is_signed ? (double)(int16_t)raw : (double)raw;
         return g.z0 + v * g.dz; /* [ref map.c:41-44]; exact for z0=0, dz=1 */
 }
@@ -544,9 +550,10 @@ __device__ __forceinline__ bool f_grid_elevation(
         if ((cache != nullptr) && (cache->id == c.id)) {
                 lo = cache->lo, hi = cache->hi;
         } else {
-                const uint16_t * p = g.nodes + c.id;
-                __builtin_memcpy(&lo, p, 4);
-                __builtin_memcpy(&hi, p + g.nx, 4);
+                global_nodes_t p = GLOBAL_NODES(g.nodes) + c.id;
+                typedef unsigned __attribute__((aligned(2))) u32_a2;
+                lo = *(const __attribute__((address_space(1))) u32_a2 *)p;
+                hi = *(const __attribute__((address_space(1))) u32_a2 *)(p + g.nx);
                 if (cache != nullptr) cache->id = c.id, cache->lo = lo, cache->hi = hi;
         }
         z = f_grid_blend(g, c, lo, hi);
@@ -758,9 +765,10 @@ __device__ __forceinline__ bool f_stack_elevation(const tamd_view & v,
                         if ((cache != nullptr) && (cache->id == id)) {
                                 lo = cache->lo, hi = cache->hi;
                         } else {
-                                const uint16_t * q = nodes + cell;
-                                __builtin_memcpy(&lo, q, 4);
-                                __builtin_memcpy(&hi, q + p.nx, 4);
+                                global_nodes_t q = GLOBAL_NODES(nodes) + cell;
+                                typedef unsigned __attribute__((aligned(2))) u32_a2;
+                                lo = *(const __attribute__((address_space(1))) u32_a2 *)q;
+                                hi = *(const __attribute__((address_space(1))) u32_a2 *)(q + p.nx);
                                 if (cache != nullptr)
                                         cache->id = id, cache->lo = lo, cache->hi = hi;
                         }
@@ -1417,40 +1425,14 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                             MODEL ? &model : nullptr);
                         my_samples++;
 
-                        /* ---- bookkeeping (cheap, may diverge) ---- */
+                        /* ---- bookkeeping ----
+                         * STEP and BISECT are handled together, as selects rather
+                         * than branches: in a busy wave every case is present in
+                         * some lane on every trip, so branching buys nothing and
+                         * costs exec-mask juggling.  Only INIT (once per ray) and
+                         * the two endings (located, done) stay branches. */
                         bool done = false, located = false;
-                        if (state == ST_BISECT) { /* [ref stepper.c:839-860] */
-                                if (s.m == m)
-                                        ds0 = t;
-                                else {
-                                        ds1 = t;
-                                        bm = s.m, bk = s.k;
-                                        if (FULL) C0 = s.lat, C1 = s.lon, C2 = s.alt, C3 = s.e0, C4 = s.e1;
-                                }
-                                /* a bracket of finite doubles is below 1e-8 after at
-                                 * most ~1100 halvings; the cap only guards against
-                                 * non-finite input (a kernel must always end) */
-                                located = !(ds1 - ds0 > 1E-08) || (++halvings > 1200);
-                        } else if (state == ST_STEP) {
-                                bx = qx, by = qy, bz = qz;
-                                if (s.m == m) { /* no boundary: the step stands */
-                                        len += ds;
-                                        k = s.k;
-                                        if (FULL) L0 = s.lat, L1 = s.lon, L2 = s.alt, L3 = s.e0, L4 = s.e1;
-                                        ds = d_step_length(v, s.alt, s.e0, s.e1, s.m);
-                                        if (++count >= max_steps) {
-                                                done = true;
-                                                my_capped++;
-                                        } else if ((ph.park_after > 0) && (count >= ph.park_after))
-                                                park = true;
-                                } else { /* [ref stepper.c:832-838] */
-                                        ds0 = -ds, ds1 = 0.;
-                                        bm = s.m, bk = s.k;
-                                        if (FULL) C0 = s.lat, C1 = s.lon, C2 = s.alt, C3 = s.e0, C4 = s.e1;
-                                        state = ST_BISECT, halvings = 0;
-                                        located = !(ds1 - ds0 > 1E-08);
-                                }
-                        } else {
+                        if (state == ST_INIT) {
                                 m = s.m, k = s.k;
                                 if (FULL) L0 = s.lat, L1 = s.lon, L2 = s.alt, L3 = s.e0, L4 = s.e1;
                                 ds = (m >= 0) ? d_step_length(v, s.alt, s.e0, s.e1, m) : 0.;
@@ -1471,6 +1453,38 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 }
                                 state = ST_STEP;
                                 done = (m < 0) || (count >= max_steps);
+                        } else {
+                                const bool stepping = (state == ST_STEP);
+                                const bool same = (s.m == m);
+                                const bool accept = stepping & same;   /* the step stands */
+                                const bool cross = stepping & !same;   /* [ref stepper.c:832-838] */
+                                const bool other = !same;              /* a sample of another medium */
+                                const double ds_next = d_step_length(v, s.alt, s.e0, s.e1, s.m);
+                                /* a STEP sample always moves B to q */
+                                bx = stepping ? qx : bx, by = stepping ? qy : by, bz = stepping ? qz : bz;
+                                len = accept ? len + ds : len;
+                                k = accept ? s.k : k;
+                                bm = other ? s.m : bm, bk = other ? s.k : bk;
+                                if (FULL) {
+                                        if (accept) L0 = s.lat, L1 = s.lon, L2 = s.alt, L3 = s.e0, L4 = s.e1;
+                                        if (other) C0 = s.lat, C1 = s.lon, C2 = s.alt, C3 = s.e0, C4 = s.e1;
+                                }
+                                /* the bracket [ref stepper.c:836, :849-858] */
+                                ds0 = cross ? -ds : ((!stepping & same) ? t : ds0);
+                                ds1 = cross ? 0. : ((!stepping & other) ? t : ds1);
+                                ds = accept ? ds_next : ds; /* a crossing keeps the tentative length */
+                                count += accept ? 1 : 0;
+                                /* a bracket of finite doubles is below 1e-8 after at
+                                 * most ~1100 halvings; the cap only guards against
+                                 * non-finite input (a kernel must always end) */
+                                halvings = stepping ? 0 : halvings + 1;
+                                state = cross ? ST_BISECT : state;
+                                const bool capped = accept & (count >= max_steps);
+                                done = capped;
+                                my_capped += capped ? 1 : 0;
+                                park = accept & !capped & (ph.park_after > 0) & (count >= ph.park_after);
+                                located = (state == ST_BISECT) &
+                                    (!(ds1 - ds0 > 1E-08) | (halvings > 1200));
                         }
                         if (located) { /* [ref stepper.c:861-863] */
                                 bx = bx + dx * ds1, by = by + dy * ds1, bz = bz + dz * ds1;
