@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--rays", type=int, default=0, help="rays per GPU (0 = the workload's)")
     ap.add_argument("--max-steps", type=int, default=100_000)
     ap.add_argument("--scatter-steps", type=int, default=256, help="c5: steps per ray")
+    ap.add_argument("--sort", type=int, default=0,
+                    help="experiment: order the rays by origin in an NxN grid of bins")
     ap.add_argument("--cpu-rays", type=int, default=1_000_000,
                     help="rays of the CPU-baseline sample (default: the whole C2 batch)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -179,6 +181,12 @@ def main():
     # ---- rays: rank r draws block r of the Philox stream; set-up on the GPU ----
     n = args.rays or default_rays
     lat, lon, az, el = sharding.rank_rays(n, rank, lat_range, lon_range)
+    if args.sort > 0:
+        nb = args.sort
+        bx = np.minimum((nb * (lon - lon_range[0]) / (lon_range[1] - lon_range[0])).astype(int), nb - 1)
+        by = np.minimum((nb * (lat - lat_range[0]) / (lat_range[1] - lat_range[0])).astype(int), nb - 1)
+        order = np.argsort(by * nb + bx, kind="stable")
+        lat, lon, az, el = lat[order], lon[order], az[order], el[order]
     dev = torch.device("cuda", local)
     t_lat, t_lon, t_az, t_el = (torch.as_tensor(v, device=dev) for v in (lat, lon, az, el))
     pos0, di = stepper.position(t_lat, t_lon, 500.0)
