@@ -13,7 +13,7 @@ for path in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
         name = row["Kernel_Name"]
         if want not in name:
             continue
-        short = name[name.find(want):].split("(")[0]
+        short = name[name.find(want):].split("(")[0] + " grid=" + row["Grid_Size"]
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for kern, ctr in acc.items():
     print(f"== {kern}")

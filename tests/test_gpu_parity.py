@@ -144,7 +144,10 @@ def test_c1_traces(golden, math):
     check_trace(t, g["r0_index"], g["r0_length"], g["r0_n_steps"], "C1 vs reference range=0")
     # the reference's default (local_range = 1) differs from it by ~1e-9 only
     check_trace(t, g["r1_index"], g["r1_length"], g["r1_n_steps"], "C1 vs reference range=1")
-    assert np.abs(t["position"] - g["r0_position"]).max() < 1e-5
+    # end points: rays that skim the ground for thousands of steps amplify any
+    # 1e-9 m difference in a sample (libm vs OCML already gives 6e-6 m in strict
+    # arithmetic); 5e-5 m over paths of kilometres is 1e-8 relative, the bar is 1e-6
+    assert np.abs(t["position"] - g["r0_position"]).max() < (5e-5 if math == "fast" else 1e-5)
     s = st.trace_stats()
     assert s["rays"] == 1000 and s["steps"] == int(np.sum(t["n_steps"])) and s["capped"] == 0
     assert 1.0 < s["samples"] / s["steps"] < 1.2  # ~1.05 samples per step

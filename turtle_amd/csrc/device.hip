@@ -227,56 +227,129 @@ __device__ __forceinline__ double f_atan2(double y, double x)
         return copysign(a, y);
 }
 
-/* Second-order local model of the transform around a reference point P0:
- * with (e, n, u) the offset from P0 in its East-North-Up frame, rn = M + h0,
- * re = N + h0 (meridional / prime-vertical radii), t = tan(lat0),
- *   lat = lat0 + n/rn - n u/rn^2 - e^2 t/(2 re rn) - n^2 M'/(2 rn^3)
- *   lon = lon0 + e/(re cos lat0) * (1 + (n t - u)/re)
- *   alt = h0 + u + e^2/(2 re) + n^2/(2 rn)
- * (the inverse, to second order, of the forward map's Taylor series).  The
- * neglected terms are O(d^3/R^2): 2e-10 m at d = 20 m, below the 1e-9 m
- * rounding noise of the closed form itself -- measured against it: <= 4e-9 m
- * out to 50 m.  For comparison the reference's own local approximation
- * (first order, finite-difference Jacobian, 1 m range, [ref stepper.c:85-171])
- * is off by 8e-8 m.  It costs ~35 instructions instead of ~230, and that is
- * what the long creeping rays that set a launch's run time need. */
-struct LocalModel {
-        double px, py, pz;           /* P0 (px = NaN: no model) */
-        double sl, cl, s, c;         /* sin/cos of its longitude, latitude */
-        double lat0, lon0, h0;       /* degrees, degrees, metres */
-        double inv_rn, inv_re, inv_rec, t, kee, mp;
+/* ---- a ray's geodetic coordinates as cubics in its path length -----------
+ *
+ * Along a straight ray q(s) = O + d s the latitude, longitude and altitude are
+ * smooth functions of the scalar s, and their Taylor series at O follow from
+ * the transform itself.  With (E, N, U) the components of the (constant)
+ * direction in the East-North-Up frame of the moving point, M and N' the
+ * meridional and prime-vertical radii,
+ *     lat' = N / (M + h)      lon' = E / ((N' + h) cos lat)      h' = U
+ *     E' = lon' (N sin lat - U cos lat)
+ *     N' = -lat' U - lon' E sin lat        U' = lat' N + lon' E cos lat
+ * and differentiating twice more gives the second and third derivatives in
+ * closed form (~130 flops, no transcendental: the sines and cosines are at
+ * hand in the closed-form transform of O).  The neglected term is c4 s^4:
+ * measured against a 40-digit evaluation of the transform, latitudes to 80
+ * degrees, any direction: 5e-12 m at 100 m, 4e-10 m at 300 m, 3e-9 m at 500 m
+ * -- the rounding noise of the closed form itself (3e-9 m).  For comparison
+ * the reference's own local approximation (first order, finite-difference
+ * Jacobian, 1 m range, [ref stepper.c:85-171]) is off by 8e-8 m.
+ *
+ * A sample on the line costs 9 FMAs instead of the ~230 instructions of the
+ * closed form; a median C2 ray (163 steps over ~3 km) needs ~7 closed forms
+ * instead of 170.  Whether a sample comes from the line depends on the ray
+ * alone (its own line and path parameter), never on its wave. */
+constexpr double kLineRange = 4000.; /* m, either side of the origin: hard limit */
+constexpr double kLineTolerance = 2e-10; /* see f_line_serves */
+
+struct RayLine {
+        double s;                /* path parameter of the ray's position B */
+        double lat[4], lon[4], alt[4]; /* degrees, degrees, metres; [k]: s^k */
+        double c4;               /* bound on the neglected term: c4 s^4 metres */
+        bool valid;
 };
 
-constexpr double kModelRadius2 = 20. * 20.; /* m^2 */
+/* Is the line good enough for a sample at parameter s that came out at
+ * `clearance` metres from the nearest boundary?  The truncation error must be
+ * below 2e-10 m (a tenth of the closed form's own rounding noise) -- or, far
+ * from any boundary, below 2e-10 OF the clearance: all such a sample decides
+ * is the length of the next step, to the same relative accuracy.  At latitude
+ * 45 this lets a line serve 500 m near the ground and ~2 km in free flight. */
+__device__ __forceinline__ bool f_line_serves(const RayLine & L, double s, double clearance)
+{
+        const double s2 = s * s;
+        return L.c4 * s2 * s2 <= kLineTolerance * fmax(clearance, 1.);
+}
 
-__device__ __forceinline__ bool f_model_eval(const LocalModel & M, double x, double y,
-    double z, double & latitude, double & longitude, double & altitude,
-    double radius2 = kModelRadius2)
+__device__ __forceinline__ void f_line_eval(const RayLine & L, double s, double & latitude,
+    double & longitude, double & altitude)
+{
+        latitude = __builtin_fma(
+            s, __builtin_fma(s, __builtin_fma(s, L.lat[3], L.lat[2]), L.lat[1]), L.lat[0]);
+        longitude = __builtin_fma(
+            s, __builtin_fma(s, __builtin_fma(s, L.lon[3], L.lon[2]), L.lon[1]), L.lon[0]);
+        altitude = __builtin_fma(
+            s, __builtin_fma(s, __builtin_fma(s, L.alt[3], L.alt[2]), L.alt[1]), L.alt[0]);
+}
+
+/* The series at a point whose transform is known: S, C = sin, cos of its
+ * latitude; sl, cl of its longitude; rn = N', rm = M; iw2 = 1 / (1 - e2 S^2). */
+__device__ __forceinline__ void f_line_build(RayLine & L, double latitude, double longitude,
+    double h, double S, double C, double sl, double cl, double rn, double rm, double iw2,
+    double dx, double dy, double dz)
 {
         constexpr double kRad2Deg = 57.29577951308232;
-        const double dx = x - M.px, dy = y - M.py, dz = z - M.pz;
-        const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
-        /* no early exit: the few dozen operations below are cheaper than a
-         * divergent branch, and a caller ignores the outputs when told `false`
-         * (r2 is NaN when there is no model) */
-        const double a = __builtin_fma(M.cl, dx, M.sl * dy);
-        const double e = __builtin_fma(M.cl, dy, -(M.sl * dx));
-        const double n = __builtin_fma(M.c, dz, -(M.s * a));
-        const double u = __builtin_fma(M.c, a, M.s * dz);
-        const double ee = e * e, nn = n * n;
-        double dphi = n * M.inv_rn;
-        dphi = dphi - dphi * u * M.inv_rn - ee * M.kee - nn * M.mp;
-        const double dlam =
-            e * M.inv_rec * __builtin_fma(__builtin_fma(n, M.t, -u), M.inv_re, 1.);
-        const double dh = u + 0.5 * __builtin_fma(ee, M.inv_re, nn * M.inv_rn);
-        latitude = __builtin_fma(dphi, kRad2Deg, M.lat0);
-        longitude = __builtin_fma(dlam, kRad2Deg, M.lon0);
-        altitude = M.h0 + dh;
-        return r2 < radius2;
+        const double e2 = kE * kE;
+        /* the direction in the local frame */
+        const double a = __builtin_fma(cl, dx, sl * dy);
+        const double E = __builtin_fma(cl, dy, -(sl * dx));
+        const double N = __builtin_fma(C, dz, -(S * a));
+        const double U = __builtin_fma(C, a, S * dz);
+        /* the radii and their first two derivatives in latitude */
+        const double SC = S * C;
+        const double k = e2 * SC * iw2;
+        const double k1 = e2 * iw2 * ((C * C - S * S) + 2. * e2 * SC * SC * iw2);
+        const double rn1 = rn * k, rm1 = 3. * rm * k;
+        const double rn2 = __builtin_fma(rn1, k, rn * k1);
+        const double rm2 = 3. * __builtin_fma(rm1, k, rm * k1);
+        const double re = rn + h;
+        const double rho = f_rcp(rm + h), nu = f_rcp(re * C);
+        /* first derivatives */
+        const double p1 = N * rho, l1 = E * nu, h1 = U;
+        const double SNCU = __builtin_fma(S, N, -(C * U));
+        const double E1 = l1 * SNCU;
+        const double N1 = -(p1 * U) - l1 * S * E;
+        const double U1 = __builtin_fma(p1, N, l1 * C * E);
+        /* second */
+        const double f = __builtin_fma(rm1, p1, h1);       /* (M + h)' */
+        const double rho1 = -(rho * rho) * f;
+        const double gq = __builtin_fma(rn1, p1, h1);
+        const double g = gq * C - re * S * p1;             /* ((N' + h) cos lat)' */
+        const double nu1 = -(nu * nu) * g;
+        const double p2 = __builtin_fma(N1, rho, N * rho1);
+        const double l2 = __builtin_fma(E1, nu, E * nu1);
+        const double h2 = U1;
+        const double E2 = l2 * SNCU + l1 * (C * p1 * N + S * N1 + S * p1 * U - C * U1);
+        const double N2 = -(p2 * U) - p1 * U1 - l2 * S * E - l1 * C * p1 * E - l1 * S * E1;
+        const double U2 = p2 * N + p1 * N1 + l2 * C * E - l1 * S * p1 * E + l1 * C * E1;
+        /* third */
+        const double f1 = rm2 * p1 * p1 + rm1 * p2 + h2;
+        const double rho2 = 2. * rho * rho * rho * f * f - rho * rho * f1;
+        const double g1 = (rn2 * p1 * p1 + rn1 * p2 + h2) * C - 2. * gq * S * p1 -
+            re * C * p1 * p1 - re * S * p2;
+        const double nu2 = 2. * nu * nu * nu * g * g - nu * nu * g1;
+        const double p3 = N2 * rho + 2. * N1 * rho1 + N * rho2;
+        const double l3 = E2 * nu + 2. * E1 * nu1 + E * nu2;
+        const double h3 = U2;
+
+        L.lat[0] = latitude, L.lat[1] = kRad2Deg * p1;
+        L.lat[2] = (0.5 * kRad2Deg) * p2, L.lat[3] = (kRad2Deg / 6.) * p3;
+        L.lon[0] = longitude, L.lon[1] = kRad2Deg * l1;
+        L.lon[2] = (0.5 * kRad2Deg) * l2, L.lon[3] = (kRad2Deg / 6.) * l3;
+        L.alt[0] = h, L.alt[1] = h1, L.alt[2] = 0.5 * h2, L.alt[3] = h3 * (1. / 6.);
+        L.s = 0.;
+        /* measured (40-digit reference, any direction, h <= 9 km): the
+         * fourth-order term is within 1e-21 (1 + tan^3 lat) s^4 metres */
+        const double tl = fabs(S) * nu * re;
+        L.c4 = 1.2e-21 * __builtin_fma(tl * tl, tl, 1.5);
+        /* not near a pole (1 / cos lat), nor where the longitude wraps */
+        L.valid = (C > 1e-3) & (fabs(longitude) < 179.9);
 }
 
 __device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
-    double & latitude, double & longitude, double & altitude, LocalModel * build = nullptr)
+    double & latitude, double & longitude, double & altitude, RayLine * build = nullptr,
+    double dx = 0., double dy = 0., double dz = 0.)
 {
         constexpr double kRad2Deg = 57.29577951308232;
         const double a = kA;
@@ -292,7 +365,7 @@ __device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
                 latitude = (z >= 0.) ? 90. : -90.;
                 longitude = 0.;
                 altitude = fabs(z) - kB;
-                if (build != nullptr) build->px = __builtin_nan("");
+                if (build != nullptr) build->valid = false;
                 return;
         }
 
@@ -343,24 +416,17 @@ __device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
         altitude = __builtin_fma(0.5 * m, p, f);
 
         if (build != nullptr) { /* everything it needs is at hand */
+                /* sine and cosine of the corrected latitude, and the radii there:
+                 * p is ~4e-8 rad, which the radii of the seed would turn into
+                 * 4e-10 of the distance along the line (2e-7 m at 500 m) */
                 const double sf = __builtin_fma(c, p, s), cf = __builtin_fma(-s, p, c);
-                const double sphi = (z < 0.) ? -sf : sf;
-                const double isg2 = isg * isg;
-                const double M = rf * isg2; /* a (1 - e2) / g^(3/2) */
-                const double inv_rn = f_rcp(M + altitude);
-                const double inv_re = f_rcp(rg + altitude);
-                const double inv_c = f_rcp(cf);
-                const bool usable = (cf > 1e-3) && (w2 != 0.);
-                build->px = usable ? x : __builtin_nan("");
-                build->py = y, build->pz = z;
-                build->sl = y * iw, build->cl = x * iw;
-                build->s = sphi, build->c = cf;
-                build->lat0 = latitude, build->lon0 = longitude, build->h0 = altitude;
-                build->inv_rn = inv_rn, build->inv_re = inv_re;
-                build->inv_rec = inv_re * inv_c;
-                build->t = sphi * inv_c;
-                build->kee = 0.5 * build->t * inv_re * inv_rn;
-                build->mp = 1.5 * e2 * M * sphi * cf * isg2 * inv_rn * inv_rn * inv_rn;
+                double sw, isw;
+                f_sqrt_rsqrt(__builtin_fma(-e2 * sf, sf, 1.), sw, isw);
+                (void)sw;
+                const double isw2 = isw * isw, rn = a * isw;
+                f_line_build(*build, latitude, longitude, altitude, (z < 0.) ? -sf : sf, cf,
+                    y * iw, x * iw, rn, a6 * rn * isw2, isw2, dx, dy, dz);
+                build->valid = build->valid & (w2 != 0.);
         }
 }
 
@@ -839,20 +905,11 @@ __device__ __forceinline__ void d_load_ctx(const tamd_view & v, OneCtx & c)
         if (MODE == TAMD_MODE_ONE_STACK) c.stack = v.stacks[mt.src];
 }
 
+/* The layers at geodetic coordinates already in s.lat, s.lon, s.alt */
 template <int MODE, bool FAST = false>
-__device__ __forceinline__ void d_sample(const tamd_view & v, const OneCtx & ctx, double x,
-    double y, double z, Sample & s, CellCache * cache = nullptr,
-    LocalModel * model = nullptr, double radius2 = kModelRadius2)
+__device__ __forceinline__ void d_classify(
+    const tamd_view & v, const OneCtx & ctx, Sample & s, CellCache * cache = nullptr)
 {
-        if (FAST && (model != nullptr)) {
-                /* inside the model's ball: ~35 instructions; else the closed
-                 * form, which re-centres the model on this point */
-                if (!f_model_eval(*model, x, y, z, s.lat, s.lon, s.alt, radius2))
-                        f_to_geodetic(x, y, z, s.lat, s.lon, s.alt, model);
-        } else if (FAST)
-                f_to_geodetic(x, y, z, s.lat, s.lon, s.alt);
-        else
-                d_to_geodetic(x, y, z, s.lat, s.lon, s.alt);
         s.m = -1, s.k = -1;
         s.e0 = -DBL_MAX, s.e1 = DBL_MAX; /* [ref stepper.c:713-716] */
 
@@ -908,6 +965,40 @@ __device__ __forceinline__ void d_sample(const tamd_view & v, const OneCtx & ctx
                         break;
                 }
         }
+}
+
+template <int MODE, bool FAST = false>
+__device__ __forceinline__ void d_sample(const tamd_view & v, const OneCtx & ctx, double x,
+    double y, double z, Sample & s, CellCache * cache = nullptr)
+{
+        if (FAST)
+                f_to_geodetic(x, y, z, s.lat, s.lon, s.alt);
+        else
+                d_to_geodetic(x, y, z, s.lat, s.lon, s.alt);
+        d_classify<MODE, FAST>(v, ctx, s, cache);
+}
+
+/* A sample of a ray that carries a line: at (x, y, z), which is parameter sl
+ * of the line.  Taken from the line if it serves; else by the closed form,
+ * which lays a new line through the point (origin there: the caller re-bases
+ * its path parameter).  Returns true in that case.  Which of the two happens
+ * depends on the ray's own line and sample only. */
+template <int MODE>
+__device__ __forceinline__ bool f_sample_on_line(const tamd_view & v, const OneCtx & ctx,
+    double x, double y, double z, double dx, double dy, double dz, RayLine & line, double sl,
+    Sample & s, CellCache * cache)
+{
+        bool serves = line.valid && (fabs(sl) <= kLineRange);
+        if (serves) {
+                f_line_eval(line, sl, s.lat, s.lon, s.alt);
+                d_classify<MODE, true>(v, ctx, s, cache);
+                serves = f_line_serves(line, sl, fmin(fabs(s.alt - s.e0), fabs(s.alt - s.e1)));
+        }
+        if (!serves) {
+                f_to_geodetic(x, y, z, s.lat, s.lon, s.alt, &line, dx, dy, dz);
+                d_classify<MODE, true>(v, ctx, s, cache);
+        }
+        return !serves;
 }
 
 /* [ref stepper.c:799-813] tentative step length from the last sample */
@@ -1229,7 +1320,7 @@ enum { TRACE_CARRY_MEDIUM = 1, TRACE_CARRY_SAMPLE = 2 };
  * longest ray.  Phase A therefore PARKS any ray that reaches `park_after` steps
  * (its state goes back to the ray arrays, its id to a list) and phase B resumes
  * the parked rays, packed into few waves that run alone on their SIMDs, with
- * the local model (MODEL) that makes a creeping ray's sample ~7x cheaper.
+ * each ray's line (MODEL; see RayLine) that makes a creeping ray's sample ~7x cheaper.
  * Which arithmetic a sample uses depends only on the ray's own step count and
  * positions, never on scheduling: results stay deterministic. */
 struct PhaseIO {
@@ -1248,8 +1339,14 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
     int flags, FullIO io, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
 {
         if (ph.n_dev != nullptr) n = (long)*ph.n_dev;
-        LocalModel model;
-        model.px = __builtin_nan("");
+        /* MODEL: the position is kept as a path length on the ray's line, B = O +
+         * d * line.s with O (in bx, by, bz) the point where the line was laid,
+         * instead of being accumulated step by step [ref stepper.c:826-830]: over
+         * the thousands of steps of the rays that reach phase B the accumulated
+         * B drifts off the ray by microns (1e-9 m of rounding per step), and
+         * line and position must agree on where a sample is */
+        RayLine line;
+        line.valid = false, line.s = 0.;
         long pool_next = 0, pool_end = 0; /* wave-uniform */
         bool exhausted = false;            /* wave-uniform */
         OneCtx ctx;
@@ -1297,7 +1394,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         if (need && (rank < avail)) {
                                 ray = pool_next + rank;
                                 if (ph.ids != nullptr) ray = ph.ids[ray];
-                                if (MODEL) model.px = __builtin_nan("");
+                                if (MODEL) line.valid = false, line.s = 0.;
                                 bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
                                 dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
                                 len = 0., count = 0, state = ST_INIT;
@@ -1340,19 +1437,23 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 if (ray >= 0) {
                                         fail = (state != ST_STEP) || (count + 1 >= max_steps);
                                         if (!fail) {
-                                                qx = bx + dx * ds, qy = by + dy * ds, qz = bz + dz * ds;
-                                                d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
-                                                    (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr,
-                                                    &model);
+                                                const double sl = line.s + ds;
+                                                qx = __builtin_fma(dx, sl, bx), qy = __builtin_fma(dy, sl, by);
+                                                qz = __builtin_fma(dz, sl, bz);
+                                                /* a new line starts at q: B is at -ds on it */
+                                                if (f_sample_on_line<MODE>(v, ctx, qx, qy, qz, dx, dy,
+                                                        dz, line, sl, s,
+                                                        (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr))
+                                                        bx = qx, by = qy, bz = qz, line.s = -ds;
                                                 fail = (s.m != m);
                                         }
                                 }
                                 /* a lane that must leave has sampled q but not moved:
                                  * the general iteration samples the same q again, and
-                                 * gets the same bits (model and cell now sit on q) */
+                                 * gets the same bits (line and cell now serve q) */
                                 if (__ballot(fail) != 0) break;
                                 if (ray >= 0) {
-                                        bx = qx, by = qy, bz = qz;
+                                        line.s += ds;
                                         len += ds;
                                         count++;
                                         k = s.k;
@@ -1362,11 +1463,9 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         }
                 }
 
-                /* The single-map case gets a leaner body still: only the model
-                 * and the cached cell (no re-centring, no fetch inside; a lane
-                 * that needs either leaves for one general iteration).  Measured
-                 * on C2: 11.4 ms per launch against 13.1 ms with the loop above
-                 * and 15.7 ms without a creep loop. */
+                /* The single-map case gets a leaner body still: only the line and
+                 * the cached cell (no closed form, no fetch inside; a lane that
+                 * needs either leaves for one general iteration). */
                 if (MODEL && (MODE == TAMD_MODE_ONE_MAP) &&
                     (__popcll(__ballot(ray >= 0)) <= kCreepLanes)) {
                         const tamd_grid & g = ctx.grid;
@@ -1374,11 +1473,10 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         for (int it = 0; it < 4096; it++) {
                                 /* no short-circuits below: every lane computes
                                  * everything (garbage is harmless, nothing is
-                                 * committed on failure) and the tests are OR-ed */
-                                const double qx = bx + dx * ds, qy = by + dy * ds,
-                                             qz = bz + dz * ds;
+                                 * committed on failure) and the tests are AND-ed */
+                                const double sl = line.s + ds;
                                 double lat, lon, alt;
-                                const bool near = f_model_eval(model, qx, qy, qz, lat, lon, alt);
+                                f_line_eval(line, sl, lat, lon, alt);
                                 /* f_grid_locate without its rim fallback: a point
                                  * within 1e-6 cell of the rim leaves the loop */
                                 CellAt c;
@@ -1391,19 +1489,21 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 c.id = (unsigned)c.iy * (unsigned)g.nx + (unsigned)c.ix;
                                 const double elevation =
                                     f_grid_blend(g, c, cell.lo, cell.hi) + ctx.offset;
+                                const double clearance = fabs(alt - elevation);
                                 const int mm = (elevation >= alt) ? 0 : 1;
                                 const bool ok = (ray >= 0) & (state == ST_STEP) &
-                                    (count + 1 < max_steps) & near & interior &
+                                    (count + 1 < max_steps) & line.valid & (fabs(sl) <= kLineRange) &
+                                    f_line_serves(line, sl, clearance) & interior &
                                     (c.id == cell.id) & (mm == m);
                                 if (__ballot((ray >= 0) & !ok) != 0) break;
                                 if (ok) {
-                                        bx = qx, by = qy, bz = qz;
+                                        line.s = sl;
                                         len += ds;
                                         count++;
                                         my_samples++;
                                         /* d_step_length for one surface: both of its
                                          * cases are |alt - elevation| */
-                                        ds = fabs(alt - elevation) * v.slope;
+                                        ds = clearance * v.slope;
                                         if (ds < v.resolution) ds = v.resolution;
                                 }
                         }
@@ -1416,13 +1516,24 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         if (state == ST_STEP) t = ds;
                         if (state == ST_BISECT) t = 0.5 * (ds0 + ds1);
                         double qx = bx, qy = by, qz = bz;
-                        if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
+                        if (MODEL && (state != ST_INIT)) {
+                                const double sl = line.s + t;
+                                qx = __builtin_fma(dx, sl, bx), qy = __builtin_fma(dy, sl, by);
+                                qz = __builtin_fma(dz, sl, bz);
+                        } else if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
                                 qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
 
                         Sample s;
-                        d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
-                            (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr,
-                            MODEL ? &model : nullptr);
+                        if (MODEL) {
+                                /* B's parameter: -t on a new line (its origin is q),
+                                 * and a STEP sample then moves B to q */
+                                if (f_sample_on_line<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line,
+                                        line.s + t, s, (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr))
+                                        bx = qx, by = qy, bz = qz, line.s = -t;
+                                if (state == ST_STEP) line.s += t;
+                        } else
+                                d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
+                                    (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr);
                         my_samples++;
 
                         /* ---- bookkeeping ----
@@ -1461,7 +1572,9 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 const bool other = !same;              /* a sample of another medium */
                                 const double ds_next = d_step_length(v, s.alt, s.e0, s.e1, s.m);
                                 /* a STEP sample always moves B to q */
-                                bx = stepping ? qx : bx, by = stepping ? qy : by, bz = stepping ? qz : bz;
+                                if (!MODEL)
+                                        bx = stepping ? qx : bx, by = stepping ? qy : by,
+                                        bz = stepping ? qz : bz;
                                 len = accept ? len + ds : len;
                                 k = accept ? s.k : k;
                                 bm = other ? s.m : bm, bk = other ? s.k : bk;
@@ -1487,7 +1600,10 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                     (!(ds1 - ds0 > 1E-08) | (halvings > 1200));
                         }
                         if (located) { /* [ref stepper.c:861-863] */
-                                bx = bx + dx * ds1, by = by + dy * ds1, bz = bz + dz * ds1;
+                                if (MODEL)
+                                        line.s += ds1;
+                                else
+                                        bx = bx + dx * ds1, by = by + dy * ds1, bz = bz + dz * ds1;
                                 len += ds + ds1;
                                 count++;
                                 m = bm, k = bk;
@@ -1495,6 +1611,10 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 done = true;
                         }
                         if (done) {
+                                if (MODEL) {
+                                        bx = __builtin_fma(dx, line.s, bx), by = __builtin_fma(dy, line.s, by);
+                                        bz = __builtin_fma(dz, line.s, bz);
+                                }
                                 pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
                                 index[2 * ray] = m, index[2 * ray + 1] = k;
                                 if (length) /* FULL, nothing stepped: the tentative length */
