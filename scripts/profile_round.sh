@@ -21,5 +21,6 @@ run B SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_
 run C FETCH_SIZE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT
 run D WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 python3 scripts/pmc_summary.py $out k_trace > $out/pmc_summary.txt
+python3 scripts/pmc_to_json.py $out/pmc_summary.txt c2 1000000 fast > $out/pmc.json
 cat $out/pmc_summary.txt
 rm -rf $out/stats $out/pmc_A $out/pmc_B $out/pmc_C $out/pmc_D

@@ -13,8 +13,8 @@
  * 1e-6).  Citations [ref FILE:LINE] are paths under the reference tree.
  *
  * The trace kernel also has a FAST arithmetic (default), a two-phase launch and
- * a local second-order model for long rays: see the comments at f_to_geodetic,
- * LocalModel, PhaseIO and k_trace, and DESIGN.md 3.1.
+ * a cubic Taylor line along each long ray: see the comments at f_to_geodetic,
+ * RayLine, PhaseIO and k_trace, and DESIGN.md 3.1.
  *
  * Kernels (one thread = one ray/point; all are fp64 VALU work with a 4-node
  * 16-bit gather per sample, see DESIGN.md for the roofline of each):
@@ -1419,15 +1419,14 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                 /* ---- creep loop (phase B, sparse waves) ---------------------------
                  * What is left at the end of a launch is a handful of rays
                  * skimming the ground with ~0.5 m steps for thousands of steps.
-                 * While every live lane of the wave is such a ray -- stepping,
-                 * inside its local model's ball and inside its cached cell --
-                 * a step needs no transform, no load and no state machine: this
-                 * loop does just that (re-centring the model or fetching a new
-                 * cell when needed), and hands any lane that needs more (a
-                 * boundary, the step cap, another state) back to the general
-                 * iteration below WITHOUT having committed that step.  It calls
-                 * the same d_sample on the same values as the general path, so
-                 * results do not depend on whether it engaged. */
+                 * While every live lane of the wave is such a ray -- stepping on
+                 * its line -- a step needs no state machine: this loop does just
+                 * that (laying a new line or fetching a new cell when needed),
+                 * and hands any lane that needs more (a boundary, the step cap,
+                 * another state) back to the general iteration below WITHOUT
+                 * having committed that step.  It calls the same functions on
+                 * the same values as the general path, so results do not depend
+                 * on whether it engaged. */
                 if (MODEL && (MODE != TAMD_MODE_ONE_MAP) &&
                     (__popcll(__ballot(ray >= 0)) <= kCreepLanes)) {
                         for (int it = 0; it < 4096; it++) {
