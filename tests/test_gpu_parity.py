@@ -428,6 +428,47 @@ def test_oracle_agrees_on_fresh_rays(math):
     m.destroy()
 
 
+@pytest.mark.parametrize("where", ["south-west", "north-80", "equator-dateline"])
+def test_long_rays_other_quadrants(where, math):
+    """Grazing rays (thousands of steps: the fast trace's second phase, where
+    coordinates come from the per-ray series) on maps in the other hemispheres, at
+    high latitude and next to the date line, against the CPU restatement."""
+    x, y = {"south-west": ((-71.0, -70.0), (-34.0, -33.0)),
+            "north-80": ((15.0, 17.0), (79.5, 80.0)),
+            "equator-dateline": ((178.9, 179.85), (-0.5, 0.5))}[where]
+    nodes = T.c1_nodes()
+    geo = O.OracleGeometry(grids=[O.default_grid(nodes, x, y, T.C1_Z)], layers=[[(O.MAP, 0, 0.0)]])
+    m = TA.Map.create(nodes, x, y, T.C1_Z)
+    st = B.c1_stepper(m)
+    rng = np.random.default_rng(5)
+    n = 1500
+    lat = rng.uniform(y[0] + 0.2 * (y[1] - y[0]), y[1] - 0.2 * (y[1] - y[0]), n)
+    lon = rng.uniform(x[0] + 0.2 * (x[1] - x[0]), x[1] - 0.2 * (x[1] - x[0]), n)
+    az = rng.uniform(0.0, 360.0, n)
+    el = rng.uniform(-3.0, 1.0, n)          # shallow: long paths close to the ground
+    pos0, di = geo.position(lat, lon, 30.0)
+    assert (di == 0).all()
+    d = O.ecef_from_horizontal(lat, lon, az, el)
+    ref = geo.trace(pos0, d, threads=4)
+    t = st.trace(pos0.copy(), d)
+    assert (ref["n_steps"] > 512).sum() > 50, "the recipe no longer reaches the second phase"
+    # These rays skim the ground for up to 1e5 steps: the most extreme of them
+    # amplify a 1e-9 m difference in one sample to centimetres (the strict
+    # arithmetic too: 2.5e-2 m on one of them).  Same rule as the full-size test:
+    # a few grazing rays may miss the bar, by no more than a few minimum steps.
+    rel = np.abs(t["length"] - ref["length"]) / np.maximum(ref["length"], 1e-300)
+    grazing = (t["index"][:, 0] != ref["index"][:, 0]) | (rel > REL)
+    assert grazing.sum() <= 2, f"{where}: {int(grazing.sum())} rays off the bar"
+    assert np.abs(t["length"] - ref["length"])[grazing].max(initial=0.0) < 0.1
+    ok = ~grazing
+    assert (np.abs(t["n_steps"] - ref["n_steps"])[ok] <= 1).all()
+    print(f"{where}: {int((ref['n_steps'] > 512).sum())} rays beyond 512 steps (max "
+          f"{int(ref['n_steps'].max())}), {int(grazing.sum())} grazing, the others: worst relative "
+          f"path-length difference {rel[ok].max():.2e}, beyond 1e-8: {int((rel[ok] > 1e-8).sum())}")
+    st.destroy()
+    m.destroy()
+
+
 def test_philox_and_isotropic_bitwise():
     import philox_ref as P
     for seed, stream, first in ((0, 0, 0), (0x5EED2026, 7, 123456789012), (2 ** 64 - 1, 2 ** 40 + 3, 5)):
