@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 TRACE_KERNEL = "k_trace (phase A: all rays up to 512 steps; phase B: the parked long rays)"
+STEP_KERNELS = "k_step + k_bisect per generation (single steps; rays that cross a boundary bisected packed)"
 
 
 def measured_traffic(workload, rays, math):
@@ -284,11 +285,12 @@ def main():
             "config": {"workload": workload_text, "rays_per_gpu": n, "max_steps": args.max_steps,
                        "slope": 0.4, "resolution": 1e-2, "math": TA.get_math(),
                        "parallelism": f"rays x{world}"},
-            "kernel": {"name": TRACE_KERNEL, "ms": kernel_ms, "launches_per_step": launches,
+            "kernel": {"name": STEP_KERNELS if scatter else TRACE_KERNEL, "ms": kernel_ms,
+                       "launches_per_step": launches,
                        "steps_per_launch": stats["steps"],
                        "samples_per_launch": stats["samples"],
                        "samples_per_step": stats["samples"] / max(1, stats["steps"]),
-                       "gpu_steps_per_s": stats["steps"] / (kernel_ms * 1e-3),
+                       "gpu_steps_per_s": stats["steps"] * launches / (kernel_ms * 1e-3),
                        "capped_rays": stats["capped"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -1,0 +1,30 @@
+"""Experiment: cost of a batch of single steps on the C5 mosaic, by generation."""
+import os, sys, tempfile
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import turtle_amd as TA
+from turtle_amd import sharding, synth
+n = int(os.environ.get("RAYS", "2000000")); side = int(os.environ.get("SIDE", "10"))
+tmp = tempfile.mkdtemp(prefix="turtle_step_")
+for i in range(side):
+    for j in range(side):
+        synth.write_hgt(tmp, 40 + i, j)
+terrain = TA.Stack(tmp, 0); st = TA.Stepper(); st.add_stack(terrain, 0.0)
+stream = torch.cuda.Stream(); torch.cuda.set_stream(stream); TA.set_stream(stream)
+lat, lon, az, el = sharding.rank_rays(n, 0, (40.0, 40.0 + side), (0.0, float(side)))
+dev = torch.device("cuda", 0)
+t = [torch.as_tensor(v, device=dev) for v in (lat, lon)]
+pos, _ = st.position(t[0], t[1], 500.0)
+def timed(f):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream); r = f(); b.record(stream); torch.cuda.synchronize(); return a.elapsed_time(b) * 1e3, r
+for rep in range(2):
+    us, state = timed(lambda: st.step(pos, None, outputs=False))
+    print(f"plain sample of {n} points: {us:.0f} us")
+d = torch.empty_like(pos)
+for k in range(40):
+    TA.isotropic(n, 1, k, 0, out=d)
+    us, state = timed(lambda: st.step(state["position"], d, resume=state))
+    if k in (0, 1, 2, 5, 10, 20, 39):
+        idx = state["index"][:, 0]
+        print(f"generation {k}: {us:.0f} us; media: outside {int((idx < 0).sum())} rock {int((idx == 0).sum())} air {int((idx == 1).sum())}; mean step {float(state['step'].mean()):.1f} m")

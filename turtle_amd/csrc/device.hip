@@ -21,9 +21,10 @@
  *   k_ecef_*        batch ECEF transforms              [ref ecef.c:41-207]
  *   k_elevation     batch bilinear lookup, map/stack   [ref map.c:229-277, stack.c:300-361]
  *   k_position      batch turtle_stepper_position      [ref stepper.c:877-931]
- *   k_step          batch sample-only turtle_stepper_step [ref stepper.c:780-821]
- *   k_trace         persistent-wave trace-to-boundary loop (the hot kernel);
- *                   single steps with a direction are traces with max_steps = 1
+ *   k_step          batch turtle_stepper_step [ref stepper.c:780-875]: the sample and
+ *                   the tentative step; rays that crossed a boundary are listed
+ *   k_bisect        ... and bisected here, packed [ref stepper.c:836-864]
+ *   k_trace         persistent-wave trace-to-boundary loop (the hot kernel)
  *   k_isotropic     Philox-4x32-10 isotropic directions (scattering harness)
  *   k_tally         hit counts + path-length histogram (uint64, exact)
  */
@@ -1196,32 +1197,76 @@ __global__ void k_position(tamd_view v, long n, const double * __restrict__ lat,
         }
 }
 
-/* One turtle_stepper_step per thread [ref stepper.c:780-875].  The bisection
- * loop diverges (only lanes that crossed a boundary run it); that is accepted
- * here because this kernel serves single-step callers.  The trace kernel
- * below is the one that keeps every lane busy. */
+__device__ __forceinline__ ull wave_sum(ull v)
+{
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        return v;
+}
+
+/* Add a block's four counters to the global ones: waves -> LDS -> 4 atomics per
+ * block.  (One set of atomics per WAVE is what a kernel can least afford: the
+ * counters share a cache line, same-line atomics complete at ~5 ns apiece, and
+ * the step kernel's 8 192 waves spent 4x their run time queueing there.) */
+__device__ __forceinline__ void block_tally(ull * __restrict__ stats, ull a, ull b, ull c, ull d)
+{
+        __shared__ ull part[4][4]; /* [wave][counter]: blocks are 256 threads */
+        a = wave_sum(a), b = wave_sum(b), c = wave_sum(c), d = wave_sum(d);
+        const int wave = (int)(threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0) part[wave][0] = a, part[wave][1] = b, part[wave][2] = c, part[wave][3] = d;
+        __syncthreads();
+        if (threadIdx.x < 4) {
+                const ull sum = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
+                    part[3][threadIdx.x];
+                if (sum != 0) atomicAdd(&stats[threadIdx.x], sum);
+        }
+}
+
+/* What a batch of single steps defers to its second pass: the rays that
+ * crossed a boundary (~2-5 % of them), and the tentative length of each. */
+struct CrossList {
+        int * ray;      /* NULL: the step kernel bisects in place */
+        double * ds;
+        ull * count;
+};
+
+/* One turtle_stepper_step per thread [ref stepper.c:780-875].  With a direction
+ * a step is one sample at the tentative position -- and, for the few rays whose
+ * medium changed there, a ~27-sample bisection.  Run inside this kernel that
+ * loop would idle the other lanes of every wave that holds such a ray (nearly
+ * all of them do), so the kernel only LISTS those rays (position moved to the
+ * tentative point, medium unchanged) and k_bisect finishes them, packed: a batch
+ * of n single steps costs n + 27 x (rays that crossed) samples, all at full
+ * lane occupancy, and exposes n-way parallelism to the gathers (a scattering
+ * Monte-Carlo over a 2.6 GB mosaic is bound by their latency).
+ * stats (or NULL): rays, steps, samples, steps that did not cross. */
 template <int MODE, bool FAST>
 __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
     double * __restrict__ pos, const double * __restrict__ dir,
     double * __restrict__ lat, double * __restrict__ lon, double * __restrict__ alt,
     double * __restrict__ elev, double * __restrict__ step, int * __restrict__ index,
-    int flags)
+    int flags, CrossList cross, ull * __restrict__ stats)
 {
         OneCtx ctx;
         d_load_ctx<MODE>(v, ctx);
-        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
-             r += (long)gridDim.x * blockDim.x) {
+        ull my_rays = 0, my_steps = 0, my_samples = 0, my_plain = 0;
+        for (long r0 = blockIdx.x * (long)blockDim.x; r0 < n; r0 += (long)gridDim.x * blockDim.x) {
+                const long r = r0 + threadIdx.x; /* whole waves go round: see the listing */
+                bool listed = false;
+                double listed_ds = 0.;
+                if (r < n) {
                 double px = pos[3 * r], py = pos[3 * r + 1], pz = pos[3 * r + 2];
                 Sample s;
-                if ((flags & TURTLE_AMD_STEP_RESUME) && (dir != nullptr)) {
-                        /* the caller hands back the sample of this position */
+                if ((flags & TURTLE_AMD_STEP_RESUME) && (dir != nullptr) && (index[2 * r] >= 0)) {
+                        /* the caller hands back the sample of this position
+                         * [ref stepper.c:708-710, :745-748] */
                         s.lat = lat ? lat[r] : 0., s.lon = lon ? lon[r] : 0.;
                         s.alt = alt[r];
                         s.e0 = elev[2 * r], s.e1 = elev[2 * r + 1];
                         s.m = index[2 * r], s.k = index[2 * r + 1];
-                        if (s.m < 0) s.e0 = s.e1 = 0.;
-                } else
+                } else {
                         d_sample<MODE, FAST>(v, ctx, px, py, pz, s);
+                        my_samples++;
+                }
 
                 double ds = 0.;
                 if (s.m >= 0) {
@@ -1230,15 +1275,28 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                                 const double dx = dir[3 * r], dy = dir[3 * r + 1],
                                              dz = dir[3 * r + 2];
                                 px += dx * ds, py += dy * ds, pz += dz * ds;
-                                const int medium0 = s.m;
-                                d_sample<MODE, FAST>(v, ctx, px, py, pz, s);
-                                if (s.m != medium0) { /* [ref stepper.c:832-864] */
+                                const int medium0 = s.m, data0 = s.k;
+                                Sample s1;
+                                d_sample<MODE, FAST>(v, ctx, px, py, pz, s1);
+                                my_samples++, my_steps++;
+                                if (s1.m == medium0) {
+                                        s = s1;
+                                        my_plain++;
+                                } else if (cross.ray != nullptr) {
+                                        /* [ref stepper.c:832-838] the second pass
+                                         * starts from here: position moved, the
+                                         * medium and data index still the old ones */
+                                        listed = true, listed_ds = ds;
+                                        s.m = medium0, s.k = data0;
+                                } else { /* [ref stepper.c:832-864] */
                                         double ds0 = -ds, ds1 = 0.;
+                                        s = s1;
                                         while (ds1 - ds0 > 1E-08) {
                                                 const double ds2 = 0.5 * (ds0 + ds1);
                                                 Sample s2;
                                                 d_sample<MODE, FAST>(v, ctx, px + dx * ds2,
                                                     py + dy * ds2, pz + dz * ds2, s2);
+                                                my_samples++;
                                                 if (s2.m == medium0)
                                                         ds0 = ds2;
                                                 else {
@@ -1252,7 +1310,97 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                                 pos[3 * r] = px, pos[3 * r + 1] = py, pos[3 * r + 2] = pz;
                         }
                 }
-                /* sample_publish [ref stepper.c:758-778] */
+                if (!listed) my_rays++;
+                /* sample_publish [ref stepper.c:758-778] (a listed ray: k_bisect's) */
+                if (!listed) {
+                        if (lat) lat[r] = s.lat;
+                        if (lon) lon[r] = s.lon;
+                        if (alt) alt[r] = s.alt;
+                        if (elev) {
+                                elev[2 * r] = (s.m >= 0) ? s.e0 : 0.;
+                                elev[2 * r + 1] = (s.m >= 0) ? s.e1 : 0.;
+                        }
+                        if (step) step[r] = ds;
+                }
+                index[2 * r] = s.m, index[2 * r + 1] = s.k;
+                }
+                /* list the rays that crossed: one atomic per wave */
+                if (cross.ray != nullptr) {
+                        const ull mask = __ballot(listed);
+                        if (mask != 0) {
+                                const int leader = __builtin_ctzll(mask);
+                                ull base = 0;
+                                if ((int)(threadIdx.x & 63) == leader)
+                                        base = atomicAdd(cross.count, (ull)__popcll(mask));
+                                base = __shfl(base, leader, 64);
+                                if (listed) {
+                                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                            __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                                        cross.ray[base + rank] = (int)r;
+                                        cross.ds[base + rank] = listed_ds;
+                                }
+                        }
+                }
+        }
+        if (stats != nullptr) block_tally(stats, my_rays, my_steps, my_samples, my_plain);
+}
+
+/* The second pass of a batch of single steps: the bisection of the listed rays
+ * [ref stepper.c:836-864], every lane busy.  The ray's position is the tentative
+ * point q, its index the medium it left; the first sample (at q again: the
+ * same arithmetic on the same point as in the first pass) is the first
+ * candidate for the medium it entered. */
+template <int MODE, bool FAST>
+__global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict__ pos,
+    const double * __restrict__ dir, double * __restrict__ lat, double * __restrict__ lon,
+    double * __restrict__ alt, double * __restrict__ elev, double * __restrict__ step,
+    int * __restrict__ index, CrossList cross, ull * __restrict__ stats)
+{
+        OneCtx ctx;
+        d_load_ctx<MODE>(v, ctx);
+        const long n = (long)*cross.count;
+        ull my_rays = 0, my_samples = 0;
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+             i += (long)gridDim.x * blockDim.x) {
+                const long r = cross.ray[i];
+                double ds = cross.ds[i];
+                double px = pos[3 * r], py = pos[3 * r + 1], pz = pos[3 * r + 2];
+                const double dx = dir[3 * r], dy = dir[3 * r + 1], dz = dir[3 * r + 2];
+                const int medium0 = index[2 * r];
+                CellCache cell = { ~0u, 0u, 0u };
+                CellCache * cache = (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr;
+                Sample s;
+                /* fast math: the bracket is a segment of the ray behind q, so the
+                 * ~27 samples come from the line laid at q (see RayLine) */
+                RayLine line;
+                double at = 0.; /* q's parameter on the line */
+                if (FAST) {
+                        f_to_geodetic(px, py, pz, s.lat, s.lon, s.alt, &line, dx, dy, dz);
+                        d_classify<MODE, true>(v, ctx, s, cache);
+                } else
+                        d_sample<MODE, false>(v, ctx, px, py, pz, s, cache);
+                double ds0 = -ds, ds1 = 0.;
+                int halvings = 0;
+                while ((ds1 - ds0 > 1E-08) && (halvings++ <= 1200)) {
+                        const double ds2 = 0.5 * (ds0 + ds1);
+                        Sample s2;
+                        if (FAST) {
+                                if (f_sample_on_line<MODE>(v, ctx, px + dx * ds2, py + dy * ds2,
+                                        pz + dz * ds2, dx, dy, dz, line, at + ds2, s2, cache))
+                                        at = -ds2; /* a new line, laid at this sample */
+                        } else
+                                d_sample<MODE, false>(v, ctx, px + dx * ds2, py + dy * ds2,
+                                    pz + dz * ds2, s2, cache);
+                        my_samples++;
+                        if (s2.m == medium0)
+                                ds0 = ds2;
+                        else {
+                                ds1 = ds2;
+                                s = s2;
+                        }
+                }
+                ds += ds1;
+                pos[3 * r] = px + dx * ds1, pos[3 * r + 1] = py + dy * ds1, pos[3 * r + 2] = pz + dz * ds1;
                 if (lat) lat[r] = s.lat;
                 if (lon) lon[r] = s.lon;
                 if (alt) alt[r] = s.alt;
@@ -1262,7 +1410,9 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                 }
                 if (step) step[r] = ds;
                 index[2 * r] = s.m, index[2 * r + 1] = s.k;
+                my_rays++;
         }
+        if (stats != nullptr) block_tally(stats, my_rays, 0, my_samples, 0);
 }
 
 /* ---- the hot kernel ---------------------------------------------------- */
@@ -1271,12 +1421,6 @@ constexpr int kChunk = 64; /* rays a wave draws from the global queue at once */
 constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many live lanes */
 
 enum { ST_INIT = 0, ST_STEP = 1, ST_BISECT = 2 };
-
-__device__ __forceinline__ ull wave_sum(ull v)
-{
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        return v;
-}
 
 /* Persistent waves; one ray per lane; ONE sample per lane per iteration.
  *
@@ -1304,17 +1448,9 @@ __device__ __forceinline__ ull wave_sum(ull v)
  *
  * Results do not depend on which lane runs a ray (rays are independent), so
  * the output is deterministic. */
-/* FULL adds what turtle_stepper_step_n needs on top of a trace: the geodetic
- * coordinates and bounding elevations of the final sample as outputs, and the
- * option to start from the sample a previous call returned (the reference's
- * `last` cache) instead of re-sampling the start point.  A batch of single
- * steps is then just a trace with max_steps = 1, and rays that cross a
- * boundary run their bisection while other lanes take other rays' steps. */
-struct FullIO {
-        double * lat, * lon, * alt, * elev;
-};
-
-enum { TRACE_CARRY_MEDIUM = 1, TRACE_CARRY_SAMPLE = 2 };
+/* TRACE_CARRY_MEDIUM: the caller knows which medium each ray is in (a trace
+ * resumed after a boundary, or after parking) */
+enum { TRACE_CARRY_MEDIUM = 1 };
 
 /* Two-phase launches.  Steps per ray are heavy-tailed (C2: median 163, max
  * 11 327) and a ray's samples are sequential, so a launch lasts as long as its
@@ -1333,11 +1469,11 @@ struct PhaseIO {
         int accumulate;      /* phase B: length / n_steps continue from the arrays */
 };
 
-template <int MODE, bool FAST, bool FULL, bool MODEL>
+template <int MODE, bool FAST, bool MODEL>
 __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
     double * __restrict__ pos, const double * __restrict__ dir, int max_steps,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
-    int flags, FullIO io, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
+    int flags, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
 {
         if (ph.n_dev != nullptr) n = (long)*ph.n_dev;
         /* MODEL: the position is kept as a path length on the ray's line, B = O +
@@ -1361,9 +1497,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         double ds = 0, ds0 = 0, ds1 = 0;
         int m = -1, k = -1, bm = -1, bk = -1, halvings = 0;
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_capped = 0;
-        /* FULL only: the sample to publish (L) and the bisection's candidate (C):
-         * lat, lon, alt, e0, e1 */
-        double L0 = 0, L1 = 0, L2 = 0, L3 = 0, L4 = 0, C0 = 0, C1 = 0, C2 = 0, C3 = 0, C4 = 0;
 
         for (;;) {
                 /* ---- refill idle lanes from the queue ---- */
@@ -1401,17 +1534,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 len = 0., count = 0, state = ST_INIT;
                                 if (ph.accumulate) len = length[ray], count = n_steps[ray];
                                 count0 = count;
-                                if (FULL && (flags & TRACE_CARRY_SAMPLE) &&
-                                    (index[2 * ray] >= 0) && (max_steps > 0)) {
-                                        /* [ref stepper.c:708-710, :745-748] */
-                                        m = index[2 * ray], k = index[2 * ray + 1];
-                                        L0 = io.lat ? io.lat[ray] : 0.;
-                                        L1 = io.lon ? io.lon[ray] : 0.;
-                                        L2 = io.alt[ray];
-                                        L3 = io.elev[2 * ray], L4 = io.elev[2 * ray + 1];
-                                        ds = d_step_length(v, L2, L3, L4, m);
-                                        state = ST_STEP;
-                                }
                         }
                         pool_next += min((long)__popcll(mask), avail);
                 }
@@ -1545,7 +1667,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         bool done = false, located = false;
                         if (state == ST_INIT) {
                                 m = s.m, k = s.k;
-                                if (FULL) L0 = s.lat, L1 = s.lon, L2 = s.alt, L3 = s.e0, L4 = s.e1;
                                 ds = (m >= 0) ? d_step_length(v, s.alt, s.e0, s.e1, m) : 0.;
                                 if ((flags & TRACE_CARRY_MEDIUM) && (m >= 0)) {
                                         /* The caller knows which medium the ray
@@ -1578,10 +1699,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 len = accept ? len + ds : len;
                                 k = accept ? s.k : k;
                                 bm = other ? s.m : bm, bk = other ? s.k : bk;
-                                if (FULL) {
-                                        if (accept) L0 = s.lat, L1 = s.lon, L2 = s.alt, L3 = s.e0, L4 = s.e1;
-                                        if (other) C0 = s.lat, C1 = s.lon, C2 = s.alt, C3 = s.e0, C4 = s.e1;
-                                }
                                 /* the bracket [ref stepper.c:836, :849-858] */
                                 ds0 = cross ? -ds : ((!stepping & same) ? t : ds0);
                                 ds1 = cross ? 0. : ((!stepping & other) ? t : ds1);
@@ -1607,7 +1724,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 len += ds + ds1;
                                 count++;
                                 m = bm, k = bk;
-                                if (FULL) L0 = C0, L1 = C1, L2 = C2, L3 = C3, L4 = C4;
                                 done = true;
                         }
                         if (done) {
@@ -1617,18 +1733,8 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 }
                                 pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
                                 index[2 * ray] = m, index[2 * ray + 1] = k;
-                                if (length) /* FULL, nothing stepped: the tentative length */
-                                        length[ray] = (FULL && (count == 0) && (m >= 0)) ? ds : len;
+                                if (length) length[ray] = len;
                                 if (n_steps) n_steps[ray] = count;
-                                if (FULL) { /* sample_publish [ref stepper.c:758-778] */
-                                        if (io.lat) io.lat[ray] = L0;
-                                        if (io.lon) io.lon[ray] = L1;
-                                        if (io.alt) io.alt[ray] = L2;
-                                        if (io.elev) {
-                                                io.elev[2 * ray] = (m >= 0) ? L3 : 0.;
-                                                io.elev[2 * ray + 1] = (m >= 0) ? L4 : 0.;
-                                        }
-                                }
                                 my_rays++;
                                 my_steps += (ull)(count - count0);
                                 ray = -1;
@@ -1656,16 +1762,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                 }
         }
 
-        my_rays = wave_sum(my_rays);
-        my_steps = wave_sum(my_steps);
-        my_samples = wave_sum(my_samples);
-        my_capped = wave_sum(my_capped);
-        if ((threadIdx.x & 63) == 0) {
-                atomicAdd(&stats[0], my_rays);
-                atomicAdd(&stats[1], my_steps);
-                atomicAdd(&stats[2], my_samples);
-                atomicAdd(&stats[3], my_capped);
-        }
+        block_tally(stats, my_rays, my_steps, my_samples, my_capped);
 }
 
 /* ---- counter-based random directions (scattering harness, config C5) ------
@@ -2027,21 +2124,35 @@ extern "C" int tamd_k_position(struct tamd_view view, long n, const double * lat
         return 0;
 }
 
-extern "C" int tamd_k_step(struct tamd_view view, long n, double * pos,
-    const double * dir, double * lat, double * lon, double * alt, double * elev,
-    double * step, int * index, int flags)
+/* n single steps: the step kernel, then -- with a direction and scratch for
+ * the list -- the bisection of the rays that crossed a boundary.  stats /
+ * queue: as for a trace (queue[2 * stride] counts the listed rays), or NULL. */
+static int run_step(struct tamd_view view, long n, double * pos, const double * dir,
+    double * lat, double * lon, double * alt, double * elev, double * step, int * index,
+    int flags, CrossList cross, ull * stats)
 {
-        if (tamd_dev_init()) return 1;
-        if (n <= 0) return 0;
         const dim3 grid(grid_for(n, 256)), block(256);
-#define STEP_CASE(MODE)                                                        \
-        do {                                                                   \
-                if (g_math_strict || !view.fast_ok)                            \
-                        hipLaunchKernelGGL((k_step<MODE, false>), grid, block, 0, g_stream,    \
-                            view, n, pos, dir, lat, lon, alt, elev, step, index, flags);       \
-                else                                                           \
-                        hipLaunchKernelGGL((k_step<MODE, true>), grid, block, 0, g_stream,     \
-                            view, n, pos, dir, lat, lon, alt, elev, step, index, flags);       \
+        const bool strict = g_math_strict || !view.fast_ok;
+#define STEP_CASE(MODE)                                                                        \
+        do {                                                                                   \
+                if (strict)                                                                    \
+                        hipLaunchKernelGGL((k_step<MODE, false>), grid, block, 0, g_stream, view, n,   \
+                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, stats);  \
+                else                                                                           \
+                        hipLaunchKernelGGL((k_step<MODE, true>), grid, block, 0, g_stream, view, n,    \
+                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, stats);  \
+                LAUNCH_CHECK("k_step");                                                        \
+                if (cross.ray == nullptr) break;                                               \
+                /* the listed rays are a few percent of n, and their number is on the        \
+                 * device: a grid for a tenth of n, striding over whatever there is */         \
+                const dim3 few(grid_for(n / 10 + 1, 256));                                     \
+                if (strict)                                                                    \
+                        hipLaunchKernelGGL((k_bisect<MODE, false>), few, block, 0, g_stream, view,     \
+                            pos, dir, lat, lon, alt, elev, step, index, cross, stats);         \
+                else                                                                           \
+                        hipLaunchKernelGGL((k_bisect<MODE, true>), few, block, 0, g_stream, view,      \
+                            pos, dir, lat, lon, alt, elev, step, index, cross, stats);         \
+                LAUNCH_CHECK("k_bisect");                                                      \
         } while (0)
         if (view.mode == TAMD_MODE_ONE_MAP)
                 STEP_CASE(TAMD_MODE_ONE_MAP);
@@ -2050,8 +2161,17 @@ extern "C" int tamd_k_step(struct tamd_view view, long n, double * pos,
         else
                 STEP_CASE(TAMD_MODE_GENERIC);
 #undef STEP_CASE
-        LAUNCH_CHECK("k_step");
         return 0;
+}
+
+extern "C" int tamd_k_step(struct tamd_view view, long n, double * pos,
+    const double * dir, double * lat, double * lon, double * alt, double * elev,
+    double * step, int * index, int flags)
+{
+        if (tamd_dev_init()) return 1;
+        if (n <= 0) return 0;
+        const CrossList none = { nullptr, nullptr, nullptr };
+        return run_step(view, n, pos, dir, lat, lon, alt, elev, step, index, flags, none, nullptr);
 }
 
 /* Waves per SIMD the trace kernel is launched with.  It is fp64-VALU bound
@@ -2076,12 +2196,12 @@ static int trace_blocks_per_cu(const void * kernel)
 extern "C" void tamd_dev_math_set(int strict) { g_math_strict = strict ? 1 : 0; }
 extern "C" int tamd_dev_math_get(void) { return g_math_strict; }
 
-template <int MODE, bool FAST, bool FULL, bool MODEL>
+template <int MODE, bool FAST, bool MODEL>
 static int launch_trace(struct tamd_view view, long n, bool n_on_device, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
-    int flags, FullIO io, PhaseIO ph, ull * stats, ull * queue)
+    int flags, PhaseIO ph, ull * stats, ull * queue)
 {
-        const void * kernel = (const void *)k_trace<MODE, FAST, FULL, MODEL>;
+        const void * kernel = (const void *)k_trace<MODE, FAST, MODEL>;
         long blocks = (long)g_cus * trace_blocks_per_cu(kernel);
         const long useful = (n + 255) / 256;
         if (!n_on_device && (blocks > useful)) blocks = useful;
@@ -2092,9 +2212,9 @@ static int launch_trace(struct tamd_view view, long n, bool n_on_device, double 
                 if (wide < (long)g_cus) wide = (long)g_cus;
                 if (blocks > wide) blocks = wide;
         }
-        hipLaunchKernelGGL((k_trace<MODE, FAST, FULL, MODEL>), dim3((unsigned)blocks),
-            dim3(256), 0, g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags,
-            io, ph, stats, queue);
+        hipLaunchKernelGGL((k_trace<MODE, FAST, MODEL>), dim3((unsigned)blocks), dim3(256), 0,
+            g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, ph, stats,
+            queue);
         LAUNCH_CHECK("k_trace");
         return 0;
 }
@@ -2112,46 +2232,27 @@ static int park_threshold(void)
         return value;
 }
 
-template <int MODE, bool FULL>
+template <int MODE>
 static int run_trace(struct tamd_view view, long n, double * pos, const double * dir,
-    int max_steps, int * index, double * length, int * n_steps, int flags, FullIO io,
-    int * parked, ull * stats, ull * queue)
+    int max_steps, int * index, double * length, int * n_steps, int flags, int * parked,
+    ull * stats, ull * queue)
 {
         const PhaseIO one = { nullptr, nullptr, nullptr, nullptr, 0, 0 };
         if (g_math_strict || !view.fast_ok)
-                return launch_trace<MODE, false, FULL, false>(view, n, false, pos, dir,
-                    max_steps, index, length, n_steps, flags, io, one, stats, queue);
+                return launch_trace<MODE, false, false>(view, n, false, pos, dir, max_steps, index,
+                    length, n_steps, flags, one, stats, queue);
         const int park = park_threshold();
-        if (FULL || (parked == nullptr) || (park <= 0) || (max_steps <= park) ||
-            (length == nullptr) || (n_steps == nullptr))
-                return launch_trace<MODE, true, FULL, false>(view, n, false, pos, dir,
-                    max_steps, index, length, n_steps, flags, io, one, stats, queue);
+        if ((parked == nullptr) || (park <= 0) || (max_steps <= park) || (length == nullptr) ||
+            (n_steps == nullptr))
+                return launch_trace<MODE, true, false>(view, n, false, pos, dir, max_steps, index,
+                    length, n_steps, flags, one, stats, queue);
         const PhaseIO a = { nullptr, nullptr, parked, queue + 2, park, 0 };
-        if (launch_trace<MODE, true, FULL, false>(view, n, false, pos, dir, max_steps, index,
-                length, n_steps, flags, io, a, stats, queue))
+        if (launch_trace<MODE, true, false>(view, n, false, pos, dir, max_steps, index, length,
+                n_steps, flags, a, stats, queue))
                 return 1;
         const PhaseIO b = { parked, queue + 2, nullptr, nullptr, 0, 1 };
-        return launch_trace<MODE, true, FULL, true>(view, n, true, pos, dir, max_steps, index,
-            length, n_steps, flags | TRACE_CARRY_MEDIUM, io, b, stats, queue + 1);
-}
-
-template <bool FULL>
-static int dispatch_trace(struct tamd_view view, long n, double * pos, const double * dir,
-    int max_steps, int * index, double * length, int * n_steps, int flags, FullIO io,
-    int * parked, ull * stats, ull * queue)
-{
-        if (tamd_dev_init()) return 1;
-        HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
-        HIP_TRY(hipMemsetAsync(queue, 0, 3 * sizeof(ull), g_stream));
-        if (n <= 0) return 0;
-        if (view.mode == TAMD_MODE_ONE_MAP)
-                return run_trace<TAMD_MODE_ONE_MAP, FULL>(view, n, pos, dir, max_steps, index,
-                    length, n_steps, flags, io, parked, stats, queue);
-        if (view.mode == TAMD_MODE_ONE_STACK)
-                return run_trace<TAMD_MODE_ONE_STACK, FULL>(view, n, pos, dir, max_steps, index,
-                    length, n_steps, flags, io, parked, stats, queue);
-        return run_trace<TAMD_MODE_GENERIC, FULL>(view, n, pos, dir, max_steps, index, length,
-            n_steps, flags, io, parked, stats, queue);
+        return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
+            n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1);
 }
 
 /* queue[0], queue[1]: work counters of the two phases; queue[2]: parked rays */
@@ -2159,22 +2260,34 @@ extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
     int flags, int * parked, unsigned long long * stats, unsigned long long * queue)
 {
-        const FullIO none = { nullptr, nullptr, nullptr, nullptr };
-        return dispatch_trace<false>(view, n, pos, dir, max_steps, index, length, n_steps,
-            (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0, none, parked, stats,
-            queue);
+        if (tamd_dev_init()) return 1;
+        HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
+        HIP_TRY(hipMemsetAsync(queue, 0, 3 * sizeof(ull), g_stream));
+        if (n <= 0) return 0;
+        const int carry = (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0;
+        if (view.mode == TAMD_MODE_ONE_MAP)
+                return run_trace<TAMD_MODE_ONE_MAP>(view, n, pos, dir, max_steps, index, length,
+                    n_steps, carry, parked, stats, queue);
+        if (view.mode == TAMD_MODE_ONE_STACK)
+                return run_trace<TAMD_MODE_ONE_STACK>(view, n, pos, dir, max_steps, index, length,
+                    n_steps, carry, parked, stats, queue);
+        return run_trace<TAMD_MODE_GENERIC>(view, n, pos, dir, max_steps, index, length, n_steps,
+            carry, parked, stats, queue);
 }
 
-/* n single steps with a direction: a FULL trace with max_steps = 1 */
+/* n single steps with a direction, in two passes (see k_step); cross_ray /
+ * cross_ds: scratch for n entries, or NULL to bisect in place */
 extern "C" int tamd_k_step_dir(struct tamd_view view, long n, double * pos,
     const double * dir, double * lat, double * lon, double * alt, double * elev,
-    double * step, int * index, int flags, unsigned long long * stats,
-    unsigned long long * queue)
+    double * step, int * index, int flags, int * cross_ray, double * cross_ds,
+    unsigned long long * stats, unsigned long long * queue)
 {
-        const FullIO io = { lat, lon, alt, elev };
-        return dispatch_trace<true>(view, n, pos, dir, 1, index, step, nullptr,
-            (flags & TURTLE_AMD_STEP_RESUME) ? TRACE_CARRY_SAMPLE : 0, io, nullptr, stats,
-            queue);
+        if (tamd_dev_init()) return 1;
+        HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
+        HIP_TRY(hipMemsetAsync(queue, 0, 3 * sizeof(ull), g_stream));
+        if (n <= 0) return 0;
+        const CrossList cross = { cross_ray, (cross_ray != nullptr) ? cross_ds : nullptr, queue + 2 };
+        return run_step(view, n, pos, dir, lat, lon, alt, elev, step, index, flags, cross, stats);
 }
 
 extern "C" int tamd_k_philox(long n, unsigned long long seed, unsigned long long stream,

@@ -130,7 +130,8 @@ struct turtle_stepper {
         size_t d_tables_size;
         struct tamd_view view;
         unsigned long long * d_stats; /* 4 stats + 3 queue counters (+1 spare) */
-        int * d_parked;               /* ids of rays handed to the second phase */
+        int * d_parked;               /* scratch of the batch calls: ray ids ... */
+        double * d_scratch_ds;        /* ... and one double each (same block) */
         long parked_capacity;
 };
 

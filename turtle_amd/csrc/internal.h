@@ -162,12 +162,14 @@ int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length,
     int * n_steps, int flags, int * parked, unsigned long long * stats,
     unsigned long long * queue);
-/* n single steps with a direction, through the trace kernel (no lane idles
- * while another bisects); `flags` are enum turtle_amd_step_flags */
+/* n single steps with a direction: the step kernel lists the rays that crossed
+ * a boundary (cross_ray / cross_ds: scratch for n entries each, or NULL to
+ * bisect in place) and a second kernel bisects them, packed; `flags` are enum
+ * turtle_amd_step_flags */
 int tamd_k_step_dir(struct tamd_view view, long n, double * pos,
     const double * dir, double * lat, double * lon, double * alt,
-    double * elev, double * step, int * index, int flags,
-    unsigned long long * stats, unsigned long long * queue);
+    double * elev, double * step, int * index, int flags, int * cross_ray,
+    double * cross_ds, unsigned long long * stats, unsigned long long * queue);
 int tamd_k_philox(long n, unsigned long long seed, unsigned long long stream,
     long first, unsigned * out);
 int tamd_k_isotropic(long n, unsigned long long seed, unsigned long long stream,

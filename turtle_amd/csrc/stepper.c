@@ -435,6 +435,30 @@ enum turtle_return turtle_stepper_position_n(struct turtle_stepper * stepper, lo
         return TURTLE_RETURN_SUCCESS;
 }
 
+/* Grow-only scratch of the batch calls: n ints (the rays a trace hands to its
+ * second phase / the rays a batch of steps defers to its bisection pass)
+ * followed by n doubles.  0 if it holds n entries; 1 if n is beyond an int
+ * (the caller does without); parked_capacity < 0 after a device failure. */
+static int tamd_stepper_scratch(struct turtle_stepper * stepper, long n)
+{
+        if (n >= 2147483647L) return 1;
+        if (n <= stepper->parked_capacity) return 0;
+        if (stepper->d_parked != NULL) {
+                tamd_dev_sync();
+                tamd_dev_free(stepper->d_parked);
+                stepper->d_parked = NULL;
+        }
+        const size_t ints = (((size_t)n * sizeof(int) + 255) / 256) * 256;
+        stepper->parked_capacity = 0;
+        if (tamd_dev_malloc((void **)&stepper->d_parked, ints + (size_t)n * sizeof(double))) {
+                stepper->parked_capacity = -1;
+                return 1;
+        }
+        stepper->d_scratch_ds = (double *)((char *)stepper->d_parked + ints);
+        stepper->parked_capacity = n;
+        return 0;
+}
+
 static enum turtle_return step_n(struct tamd_error * error, struct turtle_stepper * stepper,
     long n, double * position, const double * direction, double * latitude,
     double * longitude, double * altitude, double * elevation, double * step, int * index,
@@ -470,12 +494,16 @@ static enum turtle_return step_n(struct tamd_error * error, struct turtle_steppe
                 bad |= tamd_stage_out(&st, index, 2 * n * sizeof(int), &dix);
         }
         bad |= tamd_stage_out(&st, step, nb, &dst);
-        /* with a direction the steps run through the trace kernel; a plain
-         * sample (direction == NULL) has no bisection and keeps the simple one */
+        /* with a direction: two passes, the second for the rays that crossed a
+         * boundary (a single step bisects in place: nothing to pack) */
+        const int listed = (direction != NULL) && (n > 1) && (tamd_stepper_scratch(stepper, n) == 0);
+        if ((direction != NULL) && (n > 1) && !listed && (stepper->parked_capacity < 0)) bad = 1;
         if (bad ||
             ((direction != NULL) ?
                     tamd_k_step_dir(stepper->view, n, dp, dd, dla, dlo, dal, del, dst, dix,
-                        flags, stepper->d_stats, stepper->d_stats + 4) :
+                        flags, listed ? stepper->d_parked : NULL,
+                        listed ? stepper->d_scratch_ds : NULL, stepper->d_stats,
+                        stepper->d_stats + 4) :
                     tamd_k_step(stepper->view, n, dp, dd, dla, dlo, dal, del, dst, dix,
                         flags)) ||
             ((direction != NULL) && tamd_stage_fetch(&st, position, 3 * nb, dp)) ||
@@ -507,17 +535,8 @@ enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long 
         if ((position == NULL) || (direction == NULL) || (index == NULL))
                 return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
         FLATTEN_OR_RETURN(stepper);
-        if ((n > stepper->parked_capacity) && (n < 2147483647L)) {
-                /* scratch list for the two-phase launch (grow-only) */
-                if (stepper->d_parked != NULL) {
-                        tamd_dev_sync();
-                        tamd_dev_free(stepper->d_parked);
-                        stepper->d_parked = NULL, stepper->parked_capacity = 0;
-                }
-                if (tamd_dev_malloc((void **)&stepper->d_parked, (size_t)n * sizeof(int)))
-                        return TAMD_RAISE_DEVICE();
-                stepper->parked_capacity = n;
-        }
+        const int scratch = (tamd_stepper_scratch(stepper, n) == 0);
+        if (!scratch && (stepper->parked_capacity < 0)) return TAMD_RAISE_DEVICE();
         struct tamd_stage st;
         void *dp, *dd, *dix, *dlen, *dns;
         const size_t nb = (size_t)n * sizeof(double);
@@ -530,7 +549,7 @@ enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long 
             tamd_stage_out(&st, length, nb, &dlen) ||
             tamd_stage_out(&st, n_steps, n * sizeof(int), &dns) ||
             tamd_k_trace(stepper->view, n, dp, dd, max_steps, dix, dlen, dns, flags,
-                (n <= stepper->parked_capacity) ? stepper->d_parked : NULL, stepper->d_stats,
+                scratch ? stepper->d_parked : NULL, stepper->d_stats,
                 stepper->d_stats + 4) ||
             tamd_stage_fetch(&st, position, 3 * nb, dp) ||
             tamd_stage_fetch(&st, index, 2 * n * sizeof(int), dix) ||
