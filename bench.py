@@ -166,6 +166,7 @@ def main():
     stepper = TA.Stepper()
     if use_stack:
         terrain = TA.Stack(tmp, 0)
+        terrain.load()                         # every tile resident: no paging rounds
         stepper.add_stack(terrain, 0.0)
     else:
         terrain = TA.Map.load(os.path.join(tmp, synth.hgt_name(lat0, lon0)))

@@ -148,16 +148,27 @@ TURTLE_API void turtle_map_meta(const struct turtle_map * map,
     struct turtle_map_info * info, const char ** projection);
 
 /* ---- tile stacks [ref include/turtle.h:637-719; impl stack.c:46-450] ----
- * All tiles a stack loads become resident in HBM (288 GB holds any of the
- * configurations; `stack_size` is recorded and bounds the HOST-side copies
- * only).  Lookup semantics are the reference's with every tile loaded:
- * half-open tile boxes, exclusive outer upper edge, missing tile => inside=0. */
+ * As in the reference a stack keeps at most `stack_size` tiles in memory (no
+ * limit if <= 0), loads a tile when a query first needs it and drops the least
+ * recently used one to make room [ref stack.c:150, :399-450].  Here "memory" is
+ * HBM and a query is a batch: the kernels list the rays / points that met a
+ * tile that is not resident, the host pages those tiles in and the list runs
+ * again, until it is empty -- results are those of a stack with every tile
+ * loaded.  The effective limit is never below 16: a lookup decides a seam
+ * against the boxes of the neighbouring tiles, and the bisection of a ray's
+ * crossing can need two 3 x 3 neighbourhoods, side by side, at once.
+ * turtle_stack_load brings tiles in up to the limit (all of them without
+ * one): after it a batch over the loaded area runs in a single round.  Lookup
+ * semantics: half-open tile boxes, exclusive outer upper edge, missing tile =>
+ * inside = 0. */
 TURTLE_API enum turtle_return turtle_stack_create(struct turtle_stack ** stack,
     const char * path, int stack_size, turtle_stack_locker_t * lock,
     turtle_stack_locker_t * unlock);
 TURTLE_API void turtle_stack_destroy(struct turtle_stack ** stack);
 TURTLE_API enum turtle_return turtle_stack_clear(struct turtle_stack * stack);
 TURTLE_API enum turtle_return turtle_stack_load(struct turtle_stack * stack);
+/* extension: the number of tiles in memory right now [ref stack.h: tiles.size] */
+TURTLE_API int turtle_amd_stack_resident(const struct turtle_stack * stack);
 TURTLE_API enum turtle_return turtle_stack_elevation(
     struct turtle_stack * stack, double latitude, double longitude,
     double * elevation, int * inside);

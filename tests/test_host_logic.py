@@ -127,6 +127,30 @@ def test_stack_directory_scan(tmp_path):
     s.destroy()
 
 
+def test_stack_residency_budget(tmp_path):
+    """stack_size, turtle_stack_load / clear [ref stack.c:150, :228-297]: tiles come
+    in, in directory order, up to the limit (never below 9 here: a 3 x 3
+    neighbourhood); without a limit all of them."""
+    d = os.path.join(tmp_path, "grid")
+    tiles = [(la, lo) for la in range(40, 45) for lo in range(5, 10) if (la, lo) != (42, 7)]
+    for la, lo in tiles:
+        synth.write_hgt(d, la, lo, 1201)
+    s = TA.Stack(d, 0)
+    assert s.resident == 0          # nothing is read at creation [ref stack.c:46-226]
+    s.load()
+    assert s.resident == len(tiles) == 24
+    s.clear()
+    assert s.resident == 0
+    s.destroy()
+    for size, expect in ((20, 20), (16, 16), (2, 16)):
+        s = TA.Stack(d, size)
+        s.load()
+        assert s.resident == expect
+        s.load()                    # full: a second call changes nothing
+        assert s.resident == expect
+        s.destroy()
+
+
 def test_stack_lock_consistency_and_client(tmp_path):
     import ctypes as C
     LOCKER = C.CFUNCTYPE(C.c_int)

@@ -384,6 +384,11 @@ class Stack:
     def clear(self):
         _check(lib().turtle_stack_clear(self.h))
 
+    @property
+    def resident(self):
+        """tiles in memory right now"""
+        return int(lib().turtle_amd_stack_resident(self.h))
+
     def elevation(self, latitude, longitude):
         sp = _space_of(latitude, longitude)
         la, lo = _as(latitude, sp), _as(longitude, sp)

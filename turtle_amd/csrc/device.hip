@@ -749,10 +749,28 @@ __device__ __forceinline__ bool d_tile_holds(
  * the directory formula proposes the tile first (O(1)); its neighbours are
  * consulted only when rounding at a seam makes the box test disagree, which
  * reproduces the list scan's answer without the list. */
-/* The tile of a stack that answers for a point, or -1 [ref stack.c:300-335,
- * :413-424]: see d_stack_elevation. */
+/* Paging.  A stack may hold more tiles than it keeps in HBM (its stack_size,
+ * [ref stack.c:150, :434-443]).  In the tile table a tile that has a file but is
+ * not resident reads TAMD_TILE_PAGED; a lookup that needs such a tile -- to
+ * answer, or to decide a seam -- returns a FAULT code instead of a tile:
+ * tile_fault(table index), any value below -1.  The kernels list the rays /
+ * points that met one (page_fault), with the tiles they want; the host brings
+ * those in (evicting the least recently wanted) and runs the list again. */
+/* What a faulting lookup wants: tiles of the 3 x 3 neighbourhood of the
+ * directory slot `centre` (an index into the tile table; -1: no fault); bit
+ * 3 (j + 1) + (i + 1) of `mask` stands for the tile at centre + j * stride + i.
+ * A point inside a tile wants that tile only; a point on a seam, where the
+ * boxes of the neighbours decide, wants every neighbour that has a file: they
+ * all come in together, and none is dropped to make room for another. */
+struct TileFault {
+        int centre, mask, stride;
+};
+constexpr int kTileFault = TAMD_TILE_PAGED; /* d_stack_tile's return value then */
+
+/* The tile of a stack that answers for a point, -1 for none, or kTileFault
+ * with `f` filled in [ref stack.c:300-335, :413-424]: see d_stack_elevation. */
 __device__ __forceinline__ int d_stack_tile(const tamd_view & v, const tamd_stack & st,
-    double latitude, double longitude)
+    double latitude, double longitude, TileFault & f)
 {
         const double fx = (longitude - st.lon0) / st.dlon;
         const double fy = (latitude - st.lat0) / st.dlat;
@@ -764,8 +782,27 @@ __device__ __forceinline__ int d_stack_tile(const tamd_view & v, const tamd_stac
         const int cy = min(max((int)fy, 0), st.nlat - 1);
         const int * tiles = v.tiles + st.tile_first;
         int tile = tiles[cy * st.nlon + cx];
+        f.centre = st.tile_first + cy * st.nlon + cx, f.stride = st.nlon, f.mask = 1 << 4;
+        if (tile == TAMD_TILE_PAGED) return kTileFault;
         if ((tile < 0) || !d_tile_holds(v.grids[tile], latitude, longitude)) {
-                /* rare: a seam, the rim, or a hole in the mosaic */
+                /* rare: a seam, the rim, or a hole in the mosaic.  A neighbour
+                 * that is not resident may be the one whose box holds the point:
+                 * the whole neighbourhood has to be in memory to tell */
+                int mask = 0, paged = 0;
+                for (int j = -1; j <= 1; j++) {
+                        for (int i = -1; i <= 1; i++) {
+                                const int ix = cx + i, iy = cy + j;
+                                if ((ix < 0) || (ix >= st.nlon) || (iy < 0) || (iy >= st.nlat)) continue;
+                                const int t = tiles[iy * st.nlon + ix];
+                                if (t == TAMD_TILE_NONE) continue;
+                                mask |= 1 << (3 * (j + 1) + (i + 1));
+                                if (t == TAMD_TILE_PAGED) paged = 1;
+                        }
+                }
+                if (paged) {
+                        f.mask = mask;
+                        return kTileFault;
+                }
                 tile = -1;
                 for (int j = -1; (j <= 1) && (tile < 0); j++) {
                         for (int i = -1; (i <= 1) && (tile < 0); i++) {
@@ -781,22 +818,23 @@ __device__ __forceinline__ int d_stack_tile(const tamd_view & v, const tamd_stac
                 if (tile < 0) { /* [ref stack.c:413-424] */
                         if ((longitude < st.lon0) || (latitude < st.lat0)) return -1;
                         if (!(fx < st.nlon) || !(fy < st.nlat)) return -1;
-                        tile = tiles[(int)fy * st.nlon + (int)fx];
+                        tile = tiles[(int)fy * st.nlon + (int)fx]; /* == the centre: resident or none */
                 }
         }
         return tile;
 }
 
+/* 1: inside (z set), 0: outside (z = 0), -1: a fault (f filled in) */
 template <bool FAST = false>
-__device__ __forceinline__ bool d_stack_elevation(const tamd_view & v,
-    const tamd_stack & st, double latitude, double longitude, double & z)
+__device__ __forceinline__ int d_stack_elevation(const tamd_view & v,
+    const tamd_stack & st, double latitude, double longitude, double & z, TileFault & f)
 {
         z = 0.;
-        const int tile = d_stack_tile(v, st, latitude, longitude);
-        if (tile < 0) return false;
+        const int tile = d_stack_tile(v, st, latitude, longitude, f);
+        if (tile < 0) return (tile == kTileFault) ? -1 : 0;
         const bool inside = d_grid_elevation<FAST>(v.grids[tile], longitude, latitude, z);
         if (!inside) z = 0.;
-        return inside;
+        return inside ? 1 : 0;
 }
 
 /* Fast-math lookup in a `regular` stack (see struct tamd_stack): interior
@@ -804,9 +842,9 @@ __device__ __forceinline__ bool d_stack_elevation(const tamd_view & v,
  * pointer; anything within 1e-6 cell of a tile seam or of the directory's rim,
  * and any irregular stack, goes through the general routine above, which
  * decides seams and edges exactly as the reference does. */
-__device__ __forceinline__ bool f_stack_elevation(const tamd_view & v,
+__device__ __forceinline__ int f_stack_elevation(const tamd_view & v,
     const tamd_stack & st, double latitude, double longitude, double & z,
-    CellCache * cache)
+    CellCache * cache, TileFault & f)
 {
         if (st.regular) {
                 const tamd_grid & p = st.proto;
@@ -852,10 +890,10 @@ __device__ __forceinline__ bool f_stack_elevation(const tamd_view & v,
                         z01 = __builtin_fma(z01, p.dz, p.z0), z11 = __builtin_fma(z11, p.dz, p.z0);
                         const double gx = 1. - fxc, gy = 1. - fyc;
                         z = z00 * gx * gy + z01 * gx * fyc + z10 * fxc * gy + z11 * fxc * fyc;
-                        return true;
+                        return 1;
                 }
         }
-        return d_stack_elevation<true>(v, st, latitude, longitude, z);
+        return d_stack_elevation<true>(v, st, latitude, longitude, z, f);
 }
 
 /* ---- layered sample ---------------------------------------------------- */
@@ -864,15 +902,21 @@ struct Sample {
         double lat, lon, alt;
         double e0, e1; /* bounding elevations [ref stepper.h:93-98] */
         int m, k;      /* index[0] = medium/layer, index[1] = data */
+        TileFault fault; /* .centre >= 0: tiles have to be paged in (nothing else of
+                          * the sample is then meaningful) */
+        int slot;        /* tile-table index of the stack tile that answered (the first
+                          * stack consulted), or -1: a ray that later waits for another
+                          * tile wants this one kept too -- it is where it resumes */
 };
 
+/* 1: inside, 0: outside, -1: a fault, f filled in (stacks only) */
 template <bool FAST = false>
-__device__ __forceinline__ bool d_source_elevation(const tamd_view & v,
-    const tamd_meta & mt, double latitude, double longitude, double & z)
+__device__ __forceinline__ int d_source_elevation(const tamd_view & v,
+    const tamd_meta & mt, double latitude, double longitude, double & z, TileFault & f)
 {
         if (mt.kind == TAMD_FLAT) { /* [ref stepper.c:252-264] */
                 z = 0.;
-                return true;
+                return 1;
         } else if (mt.kind == TAMD_MAP) {
                 const tamd_grid & g = v.grids[mt.src];
                 if (g.proj.type >= 0) { /* [ref stepper.c:243-248, :304-311] */
@@ -883,7 +927,7 @@ __device__ __forceinline__ bool d_source_elevation(const tamd_view & v,
                 /* [ref stepper.c:240-241] geodetic grid: x = lon, y = lat */
                 return d_grid_elevation<FAST>(g, longitude, latitude, z);
         }
-        return d_stack_elevation<FAST>(v, v.stacks[mt.src], latitude, longitude, z);
+        return d_stack_elevation<FAST>(v, v.stacks[mt.src], latitude, longitude, z, f);
 }
 
 /* [ref stepper.c:703-756] + check_layer [ref stepper.c:687-701], always with
@@ -912,22 +956,24 @@ template <int MODE, bool FAST = false>
 __device__ __forceinline__ void d_classify(
     const tamd_view & v, const OneCtx & ctx, Sample & s, CellCache * cache = nullptr)
 {
-        s.m = -1, s.k = -1;
+        s.m = -1, s.k = -1, s.fault.centre = -1, s.slot = -1;
         s.e0 = -DBL_MAX, s.e1 = DBL_MAX; /* [ref stepper.c:713-716] */
 
         if (MODE != TAMD_MODE_GENERIC) {
                 /* one layer holding one data: no loops, no geoid */
                 double elevation;
-                bool inside;
+                int inside;
                 if (MODE == TAMD_MODE_ONE_MAP)
                         inside = FAST ?
                             f_grid_elevation(ctx.grid, s.lon, s.lat, elevation, cache) :
                             d_grid_elevation<false>(ctx.grid, s.lon, s.lat, elevation);
                 else
                         inside = FAST ?
-                            f_stack_elevation(v, ctx.stack, s.lat, s.lon, elevation, cache) :
-                            d_stack_elevation<false>(v, ctx.stack, s.lat, s.lon, elevation);
-                if (inside) {
+                            f_stack_elevation(v, ctx.stack, s.lat, s.lon, elevation, cache, s.fault) :
+                            d_stack_elevation<false>(v, ctx.stack, s.lat, s.lon, elevation, s.fault);
+                if ((MODE == TAMD_MODE_ONE_STACK) && (inside >= 0)) s.slot = s.fault.centre;
+                if ((MODE != TAMD_MODE_ONE_STACK) || (inside >= 0)) s.fault.centre = -1;
+                if (inside > 0) {
                         elevation += ctx.offset;
                         s.k = 0;
                         if (elevation >= s.alt) {
@@ -953,8 +999,15 @@ __device__ __forceinline__ void d_classify(
                 for (int j = v.layer_first[layer]; j < end; j++, data_index++) {
                         const tamd_meta mt = v.metas[j];
                         double elevation;
-                        if (!d_source_elevation<FAST>(v, mt, s.lat, s.lon, elevation))
-                                continue;
+                        TileFault f = { -1, 0, 0 };
+                        const int inside = d_source_elevation<FAST>(v, mt, s.lat, s.lon, elevation, f);
+                        if (inside < 0) { /* the layers cannot be told without that tile */
+                                s.fault = f;
+                                s.m = -1, s.k = -1;
+                                return;
+                        }
+                        if (s.slot < 0) s.slot = f.centre;
+                        if (inside == 0) continue;
                         elevation += mt.offset; /* [ref stepper.c:737] */
                         s.k = data_index;
                         if (elevation >= s.alt) { /* [ref stepper.c:690-694] */
@@ -1111,25 +1164,84 @@ __global__ void k_project(tamd_proj pr, int inverse, long n, const double * __re
         }
 }
 
+/* One round of a batch call over a geometry with paged tiles (see tile_fault).
+ * ids / n_in: the rays or points of this round (NULL: all of 0 .. n-1, the first
+ * round); faulted / n_faulted / wanted: where to list those that need a tile
+ * that is not resident, and a bitmap, over the tile table, of the tiles they
+ * need.  All NULL for a geometry with every tile resident. */
+typedef struct tamd_paging Paging;
+
+/* the whole wave calls: lists the lanes with a fault (one atomic per wave), and
+ * counts, tile by tile, how many listed items want it (the host keeps the tiles
+ * in demand) -- the tiles of the very first item of the list go into the
+ * bitmap `wanted_first` too: the host serves that one without fail, so that
+ * every round completes at least one item whatever the others compete for */
+__device__ __forceinline__ void page_fault(const Paging & pg, const TileFault & f, long r,
+    int also = -1 /* one more tile the item wants kept: where it resumes from */)
+{
+        const bool fault = f.centre >= 0;
+        const ull mask = __ballot(fault);
+        if (mask == 0) return;
+        const int leader = __builtin_ctzll(mask);
+        ull base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(pg.n_faulted, (ull)__popcll(mask));
+        base = __shfl(base, leader, 64);
+        if (fault) {
+                const int rank = __builtin_amdgcn_mbcnt_hi(
+                    (unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                pg.faulted[base + rank] = (int)r;
+                /* the item the host serves without fail: the one it named, else the
+                 * first of this list (which it will name from the next round on) */
+                const bool first = (pg.first_id >= 0) ? (r == (long)pg.first_id) : ((base + rank) == 0);
+                for (int b = 0; b < 9; b++) {
+                        if (!((f.mask >> b) & 1)) continue;
+                        const int t = f.centre + (b / 3 - 1) * f.stride + (b % 3 - 1);
+                        atomicAdd(&pg.wanted[t], 1u);
+                        if (first) atomicOr(&pg.wanted_first[t >> 5], 1u << (t & 31));
+                }
+                if (also >= 0) {
+                        atomicAdd(&pg.wanted[also], 1u);
+                        if (first) atomicOr(&pg.wanted_first[also >> 5], 1u << (also & 31));
+                }
+        }
+}
+
+/* Loop of the one-thread-per-item kernels: whole waves go round (page_fault is
+ * a wave-wide call); `r` is the item of this lane, or -1 */
+#define PAGED_ITEMS(pg, n, i0, r)                                                              \
+        const long n_items_ = ((pg).n_in != nullptr) ? (long)*(pg).n_in : (n);                 \
+        for (long i0 = blockIdx.x * (long)blockDim.x; i0 < n_items_;                           \
+             i0 += (long)gridDim.x * blockDim.x)                                               \
+                for (long i_ = i0 + threadIdx.x, r = (i_ < n_items_) ?                         \
+                             (((pg).ids != nullptr) ? (long)(pg).ids[i_] : i_) : -1, once_ = 1; \
+                     once_; once_ = 0)
+
 /* Elevation of n points on the view's first meta.  For a MAP the arguments
  * are (x, y) [ref map.c:380-385]; for a STACK (latitude, longitude)
  * [ref stack.c:338-361]. */
 __global__ void k_elevation(tamd_view v, long n, const double * __restrict__ a,
-    const double * __restrict__ b, double * __restrict__ z, int * __restrict__ inside)
+    const double * __restrict__ b, double * __restrict__ z, int * __restrict__ inside, Paging pg)
 {
         const tamd_meta mt = v.metas[0];
-        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
-             r += (long)gridDim.x * blockDim.x) {
-                double zz = 0.;
-                bool in;
-                if (mt.kind == TAMD_MAP)
-                        in = d_grid_elevation(v.grids[mt.src], a[r], b[r], zz);
-                else
-                        in = d_stack_elevation(v, v.stacks[mt.src], a[r], b[r], zz);
-                /* an outside point leaves a MAP's z untouched in the reference
-                 * and zeroes a STACK's; report 0 for both */
-                z[r] = in ? zz : 0.;
-                inside[r] = in ? 1 : 0;
+        PAGED_ITEMS(pg, n, i0, r)
+        {
+                int in = 0;
+                TileFault f = { -1, 0, 0 };
+                if (r >= 0) {
+                        double zz = 0.;
+                        if (mt.kind == TAMD_MAP)
+                                in = d_grid_elevation(v.grids[mt.src], a[r], b[r], zz) ? 1 : 0;
+                        else
+                                in = d_stack_elevation(v, v.stacks[mt.src], a[r], b[r], zz, f);
+                        if (in >= 0) f.centre = -1;
+                        if (in >= 0) {
+                                /* an outside point leaves a MAP's z untouched in the
+                                 * reference and zeroes a STACK's; report 0 for both */
+                                z[r] = in ? zz : 0.;
+                                inside[r] = in;
+                        }
+                }
+                if (pg.faulted != nullptr) page_fault(pg, f, r);
         }
 }
 
@@ -1138,62 +1250,80 @@ __global__ void k_elevation(tamd_view v, long n, const double * __restrict__ a,
  * and returns (glat, glon) [ref stack.c:364-388].  Outputs are in-out. */
 __global__ void k_gradient(tamd_view v, long n, const double * __restrict__ a,
     const double * __restrict__ b, double * __restrict__ ga, double * __restrict__ gb,
-    int * __restrict__ inside)
+    int * __restrict__ inside, Paging pg)
 {
         const tamd_meta mt = v.metas[0];
-        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
-             r += (long)gridDim.x * blockDim.x) {
-                bool in = false;
-                if (mt.kind == TAMD_MAP) {
-                        double gx = ga[r], gy = gb[r];
-                        in = d_grid_gradient(v.grids[mt.src], a[r], b[r], gx, gy);
-                        ga[r] = gx, gb[r] = gy;
-                } else {
-                        const int tile = d_stack_tile(v, v.stacks[mt.src], a[r], b[r]);
-                        if (tile < 0) {
-                                ga[r] = gb[r] = 0.; /* [ref stack.c:378-382] */
+        PAGED_ITEMS(pg, n, i0, r)
+        {
+                int tile = 0;
+                TileFault f = { -1, 0, 0 };
+                if (r >= 0) {
+                        bool in = false;
+                        if (mt.kind == TAMD_MAP) {
+                                double gx = ga[r], gy = gb[r];
+                                in = d_grid_gradient(v.grids[mt.src], a[r], b[r], gx, gy);
+                                ga[r] = gx, gb[r] = gy;
                         } else {
-                                double glat = ga[r], glon = gb[r];
-                                /* x = longitude, y = latitude; gx -> glon, gy -> glat */
-                                in = d_grid_gradient(v.grids[tile], b[r], a[r], glon, glat);
-                                ga[r] = glat, gb[r] = glon;
+                                tile = d_stack_tile(v, v.stacks[mt.src], a[r], b[r], f);
+                                if (tile != kTileFault) f.centre = -1;
+                                if (tile == -1) {
+                                        ga[r] = gb[r] = 0.; /* [ref stack.c:378-382] */
+                                } else if (tile >= 0) {
+                                        double glat = ga[r], glon = gb[r];
+                                        /* x = longitude, y = latitude; gx -> glon, gy -> glat */
+                                        in = d_grid_gradient(v.grids[tile], b[r], a[r], glon, glat);
+                                        ga[r] = glat, gb[r] = glon;
+                                }
                         }
+                        if (tile != kTileFault) inside[r] = in ? 1 : 0;
                 }
-                inside[r] = in ? 1 : 0;
+                if (pg.faulted != nullptr) page_fault(pg, f, r);
         }
 }
 
 /* [ref stepper.c:877-931] */
 __global__ void k_position(tamd_view v, long n, const double * __restrict__ lat,
     const double * __restrict__ lon, const double * __restrict__ height, int layer,
-    double * __restrict__ pos, int * __restrict__ data_index)
+    double * __restrict__ pos, int * __restrict__ data_index, Paging pg)
 {
-        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
-             r += (long)gridDim.x * blockDim.x) {
-                const double la = lat[r], lo = lon[r];
-                int found = -1, di = 0;
-                double elevation = 0.;
-                const int end = v.layer_first[layer + 1];
-                for (int j = v.layer_first[layer]; j < end; j++, di++) {
-                        const tamd_meta mt = v.metas[j];
-                        if (!d_source_elevation(v, mt, la, lo, elevation)) continue;
-                        elevation += mt.offset;
-                        if (v.geoid >= 0) { /* [ref stepper.c:905-914] */
-                                double undulation;
-                                const double l360 = (lo >= 0) ? lo : lo + 360.;
-                                if (d_grid_elevation(
-                                        v.grids[v.geoid], l360, la, undulation))
-                                        elevation += undulation;
+        PAGED_ITEMS(pg, n, i0, r)
+        {
+                TileFault fault = { -1, 0, 0 };
+                if (r >= 0) {
+                        const double la = lat[r], lo = lon[r];
+                        int found = -1, di = 0;
+                        double elevation = 0.;
+                        const int end = v.layer_first[layer + 1];
+                        for (int j = v.layer_first[layer]; j < end; j++, di++) {
+                                const tamd_meta mt = v.metas[j];
+                                TileFault f;
+                                const int in = d_source_elevation(v, mt, la, lo, elevation, f);
+                                if (in < 0) {
+                                        fault = f;
+                                        break;
+                                }
+                                if (in == 0) continue;
+                                elevation += mt.offset;
+                                if (v.geoid >= 0) { /* [ref stepper.c:905-914] */
+                                        double undulation;
+                                        const double l360 = (lo >= 0) ? lo : lo + 360.;
+                                        if (d_grid_elevation(
+                                                v.grids[v.geoid], l360, la, undulation))
+                                                elevation += undulation;
+                                }
+                                found = di;
+                                break;
                         }
-                        found = di;
-                        break;
+                        if (fault.centre < 0) {
+                                data_index[r] = found;
+                                if (found >= 0) {
+                                        double x, y, z;
+                                        d_from_geodetic(la, lo, elevation + height[r], x, y, z);
+                                        pos[3 * r] = x, pos[3 * r + 1] = y, pos[3 * r + 2] = z;
+                                }
+                        }
                 }
-                data_index[r] = found;
-                if (found >= 0) {
-                        double x, y, z;
-                        d_from_geodetic(la, lo, elevation + height[r], x, y, z);
-                        pos[3 * r] = x, pos[3 * r + 1] = y, pos[3 * r + 2] = z;
-                }
+                if (pg.faulted != nullptr) page_fault(pg, fault, r);
         }
 }
 
@@ -1244,16 +1374,18 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
     double * __restrict__ pos, const double * __restrict__ dir,
     double * __restrict__ lat, double * __restrict__ lon, double * __restrict__ alt,
     double * __restrict__ elev, double * __restrict__ step, int * __restrict__ index,
-    int flags, CrossList cross, ull * __restrict__ stats)
+    int flags, CrossList cross, Paging pg, ull * __restrict__ stats)
 {
         OneCtx ctx;
         d_load_ctx<MODE>(v, ctx);
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_plain = 0;
-        for (long r0 = blockIdx.x * (long)blockDim.x; r0 < n; r0 += (long)gridDim.x * blockDim.x) {
-                const long r = r0 + threadIdx.x; /* whole waves go round: see the listing */
+        PAGED_ITEMS(pg, n, i0, r) /* whole waves go round: see the listings */
+        {
                 bool listed = false;
                 double listed_ds = 0.;
-                if (r < n) {
+                TileFault fault = { -1, 0, 0 }; /* tiles to page in: the ray is left as it is, and listed */
+                int home = -1;
+                if (r >= 0) {
                 double px = pos[3 * r], py = pos[3 * r + 1], pz = pos[3 * r + 2];
                 Sample s;
                 if ((flags & TURTLE_AMD_STEP_RESUME) && (dir != nullptr) && (index[2 * r] >= 0)) {
@@ -1266,10 +1398,12 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                 } else {
                         d_sample<MODE, FAST>(v, ctx, px, py, pz, s);
                         my_samples++;
+                        fault = s.fault;
+                        home = s.slot;
                 }
 
                 double ds = 0.;
-                if (s.m >= 0) {
+                if ((s.m >= 0) && (fault.centre < 0)) {
                         ds = d_step_length(v, s.alt, s.e0, s.e1, s.m);
                         if (dir != nullptr) {
                                 const double dx = dir[3 * r], dy = dir[3 * r + 1],
@@ -1279,7 +1413,10 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                                 Sample s1;
                                 d_sample<MODE, FAST>(v, ctx, px, py, pz, s1);
                                 my_samples++, my_steps++;
-                                if (s1.m == medium0) {
+                                fault = s1.fault;
+                                if (fault.centre >= 0) {
+                                        /* nothing */
+                                } else if (s1.m == medium0) {
                                         s = s1;
                                         my_plain++;
                                 } else if (cross.ray != nullptr) {
@@ -1297,6 +1434,10 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                                                 d_sample<MODE, FAST>(v, ctx, px + dx * ds2,
                                                     py + dy * ds2, pz + dz * ds2, s2);
                                                 my_samples++;
+                                                if (s2.fault.centre >= 0) {
+                                                        fault = s2.fault;
+                                                        break;
+                                                }
                                                 if (s2.m == medium0)
                                                         ds0 = ds2;
                                                 else {
@@ -1307,12 +1448,13 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                                         ds += ds1;
                                         px += dx * ds1, py += dy * ds1, pz += dz * ds1;
                                 }
-                                pos[3 * r] = px, pos[3 * r + 1] = py, pos[3 * r + 2] = pz;
+                                if (fault.centre < 0) pos[3 * r] = px, pos[3 * r + 1] = py, pos[3 * r + 2] = pz;
                         }
                 }
-                if (!listed) my_rays++;
+                if (fault.centre >= 0) listed = false;
+                if (!listed && (fault.centre < 0)) my_rays++;
                 /* sample_publish [ref stepper.c:758-778] (a listed ray: k_bisect's) */
-                if (!listed) {
+                if (!listed && (fault.centre < 0)) {
                         if (lat) lat[r] = s.lat;
                         if (lon) lon[r] = s.lon;
                         if (alt) alt[r] = s.alt;
@@ -1322,8 +1464,9 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                         }
                         if (step) step[r] = ds;
                 }
-                index[2 * r] = s.m, index[2 * r + 1] = s.k;
+                if (fault.centre < 0) index[2 * r] = s.m, index[2 * r + 1] = s.k;
                 }
+                if (pg.faulted != nullptr) page_fault(pg, fault, r, home);
                 /* list the rays that crossed: one atomic per wave */
                 if (cross.ray != nullptr) {
                         const ull mask = __ballot(listed);
@@ -1354,15 +1497,19 @@ template <int MODE, bool FAST>
 __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict__ pos,
     const double * __restrict__ dir, double * __restrict__ lat, double * __restrict__ lon,
     double * __restrict__ alt, double * __restrict__ elev, double * __restrict__ step,
-    int * __restrict__ index, CrossList cross, ull * __restrict__ stats)
+    int * __restrict__ index, CrossList cross, Paging pg, ull * __restrict__ stats)
 {
         OneCtx ctx;
         d_load_ctx<MODE>(v, ctx);
         const long n = (long)*cross.count;
         ull my_rays = 0, my_samples = 0;
-        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
-             i += (long)gridDim.x * blockDim.x) {
-                const long r = cross.ray[i];
+        for (long i0 = blockIdx.x * (long)blockDim.x; i0 < n; i0 += (long)gridDim.x * blockDim.x) {
+                const long i = i0 + threadIdx.x; /* whole waves go round (page_fault) */
+                TileFault fault = { -1, 0, 0 };
+                int home = -1;
+                long r = -1;
+                if (i < n) {
+                r = cross.ray[i];
                 double ds = cross.ds[i];
                 double px = pos[3 * r], py = pos[3 * r + 1], pz = pos[3 * r + 2];
                 const double dx = dir[3 * r], dy = dir[3 * r + 1], dz = dir[3 * r + 2];
@@ -1379,9 +1526,11 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
                         d_classify<MODE, true>(v, ctx, s, cache);
                 } else
                         d_sample<MODE, false>(v, ctx, px, py, pz, s, cache);
+                fault = s.fault;
+                home = s.slot;
                 double ds0 = -ds, ds1 = 0.;
                 int halvings = 0;
-                while ((ds1 - ds0 > 1E-08) && (halvings++ <= 1200)) {
+                while ((fault.centre < 0) && (ds1 - ds0 > 1E-08) && (halvings++ <= 1200)) {
                         const double ds2 = 0.5 * (ds0 + ds1);
                         Sample s2;
                         if (FAST) {
@@ -1392,13 +1541,21 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
                                 d_sample<MODE, false>(v, ctx, px + dx * ds2, py + dy * ds2,
                                     pz + dz * ds2, s2, cache);
                         my_samples++;
-                        if (s2.m == medium0)
+                        if (s2.fault.centre >= 0) {
+                                fault = s2.fault;
+                        } else if (s2.m == medium0)
                                 ds0 = ds2;
                         else {
                                 ds1 = ds2;
                                 s = s2;
                         }
                 }
+                if (fault.centre >= 0) {
+                        /* a tile to page in (the bracket straddles a third tile): the
+                         * ray goes back before its step and is listed for the next
+                         * round, which takes it from k_step again */
+                        pos[3 * r] = px - dx * ds, pos[3 * r + 1] = py - dy * ds, pos[3 * r + 2] = pz - dz * ds;
+                } else {
                 ds += ds1;
                 pos[3 * r] = px + dx * ds1, pos[3 * r + 1] = py + dy * ds1, pos[3 * r + 2] = pz + dz * ds1;
                 if (lat) lat[r] = s.lat;
@@ -1411,6 +1568,9 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
                 if (step) step[r] = ds;
                 index[2 * r] = s.m, index[2 * r + 1] = s.k;
                 my_rays++;
+                }
+                }
+                if (pg.faulted != nullptr) page_fault(pg, fault, r, home);
         }
         if (stats != nullptr) block_tally(stats, my_rays, 0, my_samples, 0);
 }
@@ -1466,10 +1626,12 @@ struct PhaseIO {
         int * parked;        /* phase A: where to list parked rays (or NULL) */
         ull * n_parked;
         int park_after;      /* phase A: park at this step count (<= 0: never) */
-        int accumulate;      /* phase B: length / n_steps continue from the arrays */
+        int accumulate;      /* 1 (phase B): length / n_steps continue from the arrays; 2 (a
+                              * later round of a paged geometry): the tentative step too */
+        Paging pg;           /* where to list the rays that need a tile paged in (or NULLs) */
 };
 
-template <int MODE, bool FAST, bool MODEL>
+template <int MODE, bool FAST, bool MODEL, bool PAGED>
 __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
     double * __restrict__ pos, const double * __restrict__ dir, int max_steps,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
@@ -1484,6 +1646,9 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
          * line and position must agree on where a sample is */
         RayLine line;
         line.valid = false, line.s = 0.;
+        /* tiles to page in: stacks only, and only where some are not resident (the
+         * bookkeeping costs a wave per SIMD in the one-stack kernel) */
+        constexpr bool CAN_FAULT = PAGED && (MODE != TAMD_MODE_ONE_MAP);
         long pool_next = 0, pool_end = 0; /* wave-uniform */
         bool exhausted = false;            /* wave-uniform */
         OneCtx ctx;
@@ -1496,6 +1661,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         double bx = 0, by = 0, bz = 0, dx = 0, dy = 0, dz = 0, len = 0;
         double ds = 0, ds0 = 0, ds1 = 0;
         int m = -1, k = -1, bm = -1, bk = -1, halvings = 0;
+        int home = -1; /* CAN_FAULT: the tile of the ray's last sample (see Sample.slot) */
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_capped = 0;
 
         for (;;) {
@@ -1534,6 +1700,17 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 len = 0., count = 0, state = ST_INIT;
                                 if (ph.accumulate) len = length[ray], count = n_steps[ray];
                                 count0 = count;
+                                if (CAN_FAULT && (ph.accumulate == 2)) {
+                                        /* a ray that waited for a tile: it carries on
+                                         * with the step it was about to take (a fresh
+                                         * sample of its position could need the tile it
+                                         * came from, which may be gone) */
+                                        const double w = ph.pg.tentative[ray];
+                                        if (w >= 0.) {
+                                                state = ST_STEP, ds = w;
+                                                m = index[2 * ray], k = index[2 * ray + 1];
+                                        }
+                                }
                         }
                         pool_next += min((long)__popcll(mask), avail);
                 }
@@ -1567,7 +1744,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                                         dz, line, sl, s,
                                                         (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr))
                                                         bx = qx, by = qy, bz = qz, line.s = -ds;
-                                                fail = (s.m != m);
+                                                fail = (s.m != m) || (s.fault.centre >= 0);
                                         }
                                 }
                                 /* a lane that must leave has sampled q but not moved:
@@ -1632,6 +1809,8 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                 }
 
                 bool park = false;
+                TileFault fault = { -1, 0, 0 }; /* the tiles to page in, if any */
+                double fx = 0, fy = 0, fz = 0; /* where the ray goes back to, then */
                 if (ray >= 0) {
                         /* ---- one sample at q = B + d * t ---- */
                         double t = 0.;
@@ -1657,6 +1836,22 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
                                     (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr);
                         my_samples++;
+                        if (CAN_FAULT && (s.fault.centre >= 0)) {
+                                /* a tile that is not resident: the ray goes back to
+                                 * the arrays as it was BEFORE this sample (before the
+                                 * crossing step, if it was bisecting: the bracket is
+                                 * not kept) and on the list for the next round */
+                                fault = s.fault;
+                                if (state == ST_INIT) home = -1; /* a new ray: nothing to keep */
+                                double back = (state == ST_BISECT) ? ds : 0.;
+                                if (MODEL) {
+                                        back += (state == ST_STEP) ? t : 0.;
+                                        const double sb = line.s - back;
+                                        fx = __builtin_fma(dx, sb, bx), fy = __builtin_fma(dy, sb, by);
+                                        fz = __builtin_fma(dz, sb, bz);
+                                } else
+                                        fx = bx - dx * back, fy = by - dy * back, fz = bz - dz * back;
+                        }
 
                         /* ---- bookkeeping ----
                          * STEP and BISECT are handled together, as selects rather
@@ -1665,7 +1860,10 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                          * costs exec-mask juggling.  Only INIT (once per ray) and
                          * the two endings (located, done) stay branches. */
                         bool done = false, located = false;
-                        if (state == ST_INIT) {
+                        if (CAN_FAULT && (fault.centre < 0) && (state == ST_STEP)) home = s.slot;
+                        if (fault.centre >= 0) {
+                                /* nothing: see below */
+                        } else if (state == ST_INIT) {
                                 m = s.m, k = s.k;
                                 ds = (m >= 0) ? d_step_length(v, s.alt, s.e0, s.e1, m) : 0.;
                                 if ((flags & TRACE_CARRY_MEDIUM) && (m >= 0)) {
@@ -1759,6 +1957,26 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 my_steps += (ull)(count - count0);
                                 ray = -1;
                         }
+                }
+                /* ---- list the rays that wait for a tile (whole wave takes part) ---- */
+                if (CAN_FAULT && (ph.pg.faulted != nullptr)) {
+                        const bool waits = fault.centre >= 0;
+                        if (waits) {
+                                pos[3 * ray] = fx, pos[3 * ray + 1] = fy, pos[3 * ray + 2] = fz;
+                                if (state != ST_INIT) /* else: what the caller gave, or nothing */
+                                        index[2 * ray] = m, index[2 * ray + 1] = k;
+                                else if (!(flags & TRACE_CARRY_MEDIUM))
+                                        index[2 * ray] = -1, index[2 * ray + 1] = -1;
+                                if (length) length[ray] = len;
+                                if (n_steps) n_steps[ray] = count;
+                                /* the step it was about to take (a bisecting ray went
+                                 * back before its crossing step: the same one) */
+                                ph.pg.tentative[ray] = (state != ST_INIT) ? ds : -1.;
+                                my_steps += (ull)(count - count0);
+                        }
+                        /* a bisecting ray also wants the tile of its crossing sample */
+                        page_fault(ph.pg, fault, ray, (state == ST_BISECT) ? home : -1);
+                        if (waits) ray = -1;
                 }
         }
 
@@ -2080,12 +2298,12 @@ extern "C" int tamd_k_ecef_to_horizontal(long n, const double * lat,
 }
 
 extern "C" int tamd_k_elevation(struct tamd_view view, long n, const double * a,
-    const double * b, double * z, int * inside)
+    const double * b, double * z, int * inside, struct tamd_paging pg)
 {
         if (tamd_dev_init()) return 1;
         if (n <= 0) return 0;
         hipLaunchKernelGGL(k_elevation, dim3(grid_for(n, 256)), dim3(256), 0, g_stream,
-            view, n, a, b, z, inside);
+            view, n, a, b, z, inside, pg);
         LAUNCH_CHECK("k_elevation");
         return 0;
 }
@@ -2102,24 +2320,24 @@ extern "C" int tamd_k_project(struct tamd_proj proj, int inverse, long n, const 
 }
 
 extern "C" int tamd_k_gradient(struct tamd_view view, long n, const double * a,
-    const double * b, double * ga, double * gb, int * inside)
+    const double * b, double * ga, double * gb, int * inside, struct tamd_paging pg)
 {
         if (tamd_dev_init()) return 1;
         if (n <= 0) return 0;
         hipLaunchKernelGGL(k_gradient, dim3(grid_for(n, 256)), dim3(256), 0, g_stream, view,
-            n, a, b, ga, gb, inside);
+            n, a, b, ga, gb, inside, pg);
         LAUNCH_CHECK("k_gradient");
         return 0;
 }
 
 extern "C" int tamd_k_position(struct tamd_view view, long n, const double * lat,
     const double * lon, const double * height, int layer, double * pos,
-    int * data_index)
+    int * data_index, struct tamd_paging pg)
 {
         if (tamd_dev_init()) return 1;
         if (n <= 0) return 0;
         hipLaunchKernelGGL(k_position, dim3(grid_for(n, 256)), dim3(256), 0, g_stream,
-            view, n, lat, lon, height, layer, pos, data_index);
+            view, n, lat, lon, height, layer, pos, data_index, pg);
         LAUNCH_CHECK("k_position");
         return 0;
 }
@@ -2129,7 +2347,7 @@ extern "C" int tamd_k_position(struct tamd_view view, long n, const double * lat
  * queue: as for a trace (queue[2 * stride] counts the listed rays), or NULL. */
 static int run_step(struct tamd_view view, long n, double * pos, const double * dir,
     double * lat, double * lon, double * alt, double * elev, double * step, int * index,
-    int flags, CrossList cross, ull * stats)
+    int flags, CrossList cross, Paging pg, ull * stats)
 {
         const dim3 grid(grid_for(n, 256)), block(256);
         const bool strict = g_math_strict || !view.fast_ok;
@@ -2137,10 +2355,10 @@ static int run_step(struct tamd_view view, long n, double * pos, const double * 
         do {                                                                                   \
                 if (strict)                                                                    \
                         hipLaunchKernelGGL((k_step<MODE, false>), grid, block, 0, g_stream, view, n,   \
-                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, stats);  \
+                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats);      \
                 else                                                                           \
                         hipLaunchKernelGGL((k_step<MODE, true>), grid, block, 0, g_stream, view, n,    \
-                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, stats);  \
+                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats);      \
                 LAUNCH_CHECK("k_step");                                                        \
                 if (cross.ray == nullptr) break;                                               \
                 /* the listed rays are a few percent of n, and their number is on the        \
@@ -2148,10 +2366,10 @@ static int run_step(struct tamd_view view, long n, double * pos, const double * 
                 const dim3 few(grid_for(n / 10 + 1, 256));                                     \
                 if (strict)                                                                    \
                         hipLaunchKernelGGL((k_bisect<MODE, false>), few, block, 0, g_stream, view,     \
-                            pos, dir, lat, lon, alt, elev, step, index, cross, stats);         \
+                            pos, dir, lat, lon, alt, elev, step, index, cross, pg, stats);     \
                 else                                                                           \
                         hipLaunchKernelGGL((k_bisect<MODE, true>), few, block, 0, g_stream, view,      \
-                            pos, dir, lat, lon, alt, elev, step, index, cross, stats);         \
+                            pos, dir, lat, lon, alt, elev, step, index, cross, pg, stats);     \
                 LAUNCH_CHECK("k_bisect");                                                      \
         } while (0)
         if (view.mode == TAMD_MODE_ONE_MAP)
@@ -2166,12 +2384,13 @@ static int run_step(struct tamd_view view, long n, double * pos, const double * 
 
 extern "C" int tamd_k_step(struct tamd_view view, long n, double * pos,
     const double * dir, double * lat, double * lon, double * alt, double * elev,
-    double * step, int * index, int flags)
+    double * step, int * index, int flags, struct tamd_paging pg)
 {
         if (tamd_dev_init()) return 1;
         if (n <= 0) return 0;
         const CrossList none = { nullptr, nullptr, nullptr };
-        return run_step(view, n, pos, dir, lat, lon, alt, elev, step, index, flags, none, nullptr);
+        return run_step(view, n, pos, dir, lat, lon, alt, elev, step, index, flags, none, pg,
+            nullptr);
 }
 
 /* Waves per SIMD the trace kernel is launched with.  It is fp64-VALU bound
@@ -2196,12 +2415,12 @@ static int trace_blocks_per_cu(const void * kernel)
 extern "C" void tamd_dev_math_set(int strict) { g_math_strict = strict ? 1 : 0; }
 extern "C" int tamd_dev_math_get(void) { return g_math_strict; }
 
-template <int MODE, bool FAST, bool MODEL>
-static int launch_trace(struct tamd_view view, long n, bool n_on_device, double * pos,
+template <int MODE, bool FAST, bool MODEL, bool PAGED>
+static int launch_trace_(struct tamd_view view, long n, bool n_on_device, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
     int flags, PhaseIO ph, ull * stats, ull * queue)
 {
-        const void * kernel = (const void *)k_trace<MODE, FAST, MODEL>;
+        const void * kernel = (const void *)k_trace<MODE, FAST, MODEL, PAGED>;
         long blocks = (long)g_cus * trace_blocks_per_cu(kernel);
         const long useful = (n + 255) / 256;
         if (!n_on_device && (blocks > useful)) blocks = useful;
@@ -2212,11 +2431,24 @@ static int launch_trace(struct tamd_view view, long n, bool n_on_device, double 
                 if (wide < (long)g_cus) wide = (long)g_cus;
                 if (blocks > wide) blocks = wide;
         }
-        hipLaunchKernelGGL((k_trace<MODE, FAST, MODEL>), dim3((unsigned)blocks), dim3(256), 0,
-            g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, ph, stats,
+        hipLaunchKernelGGL((k_trace<MODE, FAST, MODEL, PAGED>), dim3((unsigned)blocks), dim3(256),
+            0, g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, ph, stats,
             queue);
         LAUNCH_CHECK("k_trace");
         return 0;
+}
+
+template <int MODE, bool FAST, bool MODEL>
+static int launch_trace(struct tamd_view view, long n, bool n_on_device, double * pos,
+    const double * dir, int max_steps, int * index, double * length, int * n_steps,
+    int flags, PhaseIO ph, ull * stats, ull * queue)
+{
+        if ((MODE != TAMD_MODE_ONE_MAP) && (ph.pg.faulted != nullptr))
+                return launch_trace_<MODE, FAST, MODEL, (MODE != TAMD_MODE_ONE_MAP)>(view, n,
+                    n_on_device, pos, dir, max_steps, index, length, n_steps, flags, ph, stats,
+                    queue);
+        return launch_trace_<MODE, FAST, MODEL, false>(view, n, n_on_device, pos, dir, max_steps,
+            index, length, n_steps, flags, ph, stats, queue);
 }
 
 /* Step count at which phase A parks a ray (fast math only; 0 disables the
@@ -2232,47 +2464,54 @@ static int park_threshold(void)
         return value;
 }
 
+/* One round of a trace: all the rays (pg.ids == NULL), or the ones the last
+ * round listed because they needed a tile (they carry on from the arrays). */
 template <int MODE>
 static int run_trace(struct tamd_view view, long n, double * pos, const double * dir,
     int max_steps, int * index, double * length, int * n_steps, int flags, int * parked,
-    ull * stats, ull * queue)
+    Paging pg, ull * stats, ull * queue)
 {
-        const PhaseIO one = { nullptr, nullptr, nullptr, nullptr, 0, 0 };
+        const bool again = (pg.ids != nullptr);
+        if (again) flags |= TRACE_CARRY_MEDIUM;
+        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, again ? 2 : 0, pg };
         if (g_math_strict || !view.fast_ok)
-                return launch_trace<MODE, false, false>(view, n, false, pos, dir, max_steps, index,
+                return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
         const int park = park_threshold();
         if ((parked == nullptr) || (park <= 0) || (max_steps <= park) || (length == nullptr) ||
             (n_steps == nullptr))
-                return launch_trace<MODE, true, false>(view, n, false, pos, dir, max_steps, index,
+                return launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
-        const PhaseIO a = { nullptr, nullptr, parked, queue + 2, park, 0 };
-        if (launch_trace<MODE, true, false>(view, n, false, pos, dir, max_steps, index, length,
+        const PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, again ? 2 : 0, pg };
+        if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
                 n_steps, flags, a, stats, queue))
                 return 1;
-        const PhaseIO b = { parked, queue + 2, nullptr, nullptr, 0, 1 };
+        const PhaseIO b = { parked, queue + 2, nullptr, nullptr, 0, 1, pg };
         return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
             n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1);
 }
 
-/* queue[0], queue[1]: work counters of the two phases; queue[2]: parked rays */
+/* queue[0], queue[1]: work counters of the two phases; queue[2]: parked rays.
+ * pg: the round of a paged geometry (paging.c), all NULL otherwise; the
+ * counters in `stats` add up over the rounds of a call. */
 extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
-    int flags, int * parked, unsigned long long * stats, unsigned long long * queue)
+    int flags, int * parked, struct tamd_paging pg, unsigned long long * stats,
+    unsigned long long * queue)
 {
         if (tamd_dev_init()) return 1;
-        HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
+        if (pg.ids == nullptr) HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
         HIP_TRY(hipMemsetAsync(queue, 0, 3 * sizeof(ull), g_stream));
         if (n <= 0) return 0;
         const int carry = (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0;
         if (view.mode == TAMD_MODE_ONE_MAP)
                 return run_trace<TAMD_MODE_ONE_MAP>(view, n, pos, dir, max_steps, index, length,
-                    n_steps, carry, parked, stats, queue);
+                    n_steps, carry, parked, pg, stats, queue);
         if (view.mode == TAMD_MODE_ONE_STACK)
                 return run_trace<TAMD_MODE_ONE_STACK>(view, n, pos, dir, max_steps, index, length,
-                    n_steps, carry, parked, stats, queue);
+                    n_steps, carry, parked, pg, stats, queue);
         return run_trace<TAMD_MODE_GENERIC>(view, n, pos, dir, max_steps, index, length, n_steps,
-            carry, parked, stats, queue);
+            carry, parked, pg, stats, queue);
 }
 
 /* n single steps with a direction, in two passes (see k_step); cross_ray /
@@ -2280,14 +2519,15 @@ extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
 extern "C" int tamd_k_step_dir(struct tamd_view view, long n, double * pos,
     const double * dir, double * lat, double * lon, double * alt, double * elev,
     double * step, int * index, int flags, int * cross_ray, double * cross_ds,
-    unsigned long long * stats, unsigned long long * queue)
+    struct tamd_paging pg, unsigned long long * stats, unsigned long long * queue)
 {
         if (tamd_dev_init()) return 1;
-        HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
+        if (pg.ids == nullptr) HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
         HIP_TRY(hipMemsetAsync(queue, 0, 3 * sizeof(ull), g_stream));
         if (n <= 0) return 0;
         const CrossList cross = { cross_ray, (cross_ray != nullptr) ? cross_ds : nullptr, queue + 2 };
-        return run_step(view, n, pos, dir, lat, lon, alt, elev, step, index, flags, cross, stats);
+        return run_step(view, n, pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg,
+            stats);
 }
 
 extern "C" int tamd_k_philox(long n, unsigned long long seed, unsigned long long stream,

@@ -87,12 +87,34 @@ struct turtle_stack {
         char * root;
         char ** path;             /* [lat_n * long_n] file of each slot or NULL */
         struct turtle_map ** tile; /* [lat_n * long_n] loaded tile or NULL */
-        int n_loaded;
+        unsigned long * stamp;    /* [lat_n * long_n] when the tile was last wanted */
+        unsigned long clock;
+        int n_loaded, n_files;
+        /* device tables of the stack's own batch calls (stack.c: stack_view) */
+        void * d_tables;
+        size_t d_tables_size;
+        unsigned long view_epoch;
+        struct tamd_view view;
 };
 
-/* load every tile that has a file (HBM holds them all); 0 on success, else an
- * enum turtle_return with a message in `message` */
-int tamd_stack_load_all(struct turtle_stack * stack, char * message, size_t size);
+/* Tiles the stack may keep in memory [ref stack.c:150]: max_size (at least
+ * TAMD_STACK_FLOOR), or no limit */
+#define TAMD_STACK_FLOOR 16
+int tamd_stack_budget(const struct turtle_stack * stack);
+/* Are there tiles with a file that are not in memory? */
+int tamd_stack_is_paged(const struct turtle_stack * stack);
+/* [ref stack.c:257-297] tiles in directory order until the budget is reached;
+ * 0 on success, else an enum turtle_return with a message in `message` */
+int tamd_stack_preload(struct turtle_stack * stack, char * message, size_t size);
+/* Bring in tiles that a round wanted: wanted[first_bit + slot] = how many of
+ * its listed items want the tile, resident or not.  Beyond the budget a tile in
+ * less demand makes room -- the least recently wanted among those nobody wants
+ * [ref stack.c:433-443].  The tiles of the bitmap `wanted_first` (the first
+ * item of the list: at most a 3 x 3 neighbourhood and one more) come in without
+ * fail, whatever has to go.  Returns the number of tiles loaded, or minus an
+ * enum turtle_return with `message` set. */
+int tamd_stack_page_in(struct turtle_stack * stack, const unsigned * wanted,
+    const unsigned * wanted_first, int first_bit, char * message, size_t size);
 
 struct turtle_client {
         struct turtle_stack * stack;
@@ -129,6 +151,7 @@ struct turtle_stepper {
         void * d_tables;
         size_t d_tables_size;
         struct tamd_view view;
+        int n_table;                  /* entries of the tile table (all stacks) */
         unsigned long long * d_stats; /* 4 stats + 3 queue counters (+1 spare) */
         int * d_parked;               /* scratch of the batch calls: ray ids ... */
         double * d_scratch_ds;        /* ... and one double each (same block) */
@@ -140,6 +163,24 @@ extern unsigned long tamd_geometry_epoch;
 
 /* Builds/refreshes stepper->view; returns an enum turtle_return and a message */
 int tamd_stepper_flatten(struct turtle_stepper * stepper, char * message, size_t size);
+
+/* ---- rounds of a batch call over paged stacks (paging.c) ------------------- */
+struct tamd_pager {
+        int active, rounds;
+        int * d_list[2];
+        unsigned long long * d_count;
+        unsigned * d_wanted;
+        unsigned * wanted; /* host copies after tamd_pager_collect: demand per tile ... */
+        unsigned * wanted_first; /* ... and the bitmap of the first item's tiles */
+        unsigned * pinned; /* every tile the item served without fail has asked for so far */
+        int first_id;      /* that item (-1: the first of the next list) */
+        size_t words, first_offset, bitmap_words;
+};
+int tamd_pager_begin(struct tamd_pager * pager, long n, int table_entries);
+int tamd_pager_round(struct tamd_pager * pager, struct tamd_paging * pg);
+int tamd_pager_collect(struct tamd_pager * pager, unsigned long long * n_faulted);
+void tamd_pager_end(struct tamd_pager * pager);
+#define TAMD_PAGING_ROUNDS 100000 /* a batch needs about one round per tile it touches */
 
 /* ---- HOST/DEVICE array staging for the batch calls ----------------------- */
 struct tamd_stage {

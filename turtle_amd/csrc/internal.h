@@ -74,6 +74,10 @@ struct tamd_stack {
 
 enum tamd_kind { TAMD_FLAT = 0, TAMD_MAP = 1, TAMD_STACK = 2 };
 
+/* values of the tile table (tamd_view.tiles) besides a grid index */
+#define TAMD_TILE_NONE (-1)  /* no file for this slot */
+#define TAMD_TILE_PAGED (-2) /* a file, not resident: see "Paging" in device.hip */
+
 /* One (data, offset) entry of a layer [ref src/turtle/stepper.h:80-85], stored
  * in the reference's iteration order: last added first [ref stepper.c:722-724] */
 struct tamd_meta {
@@ -131,6 +135,21 @@ int tamd_dev_zero(void * dst, size_t bytes);                   /* stream-ordered
 void tamd_scratch_reset(void);
 int tamd_scratch_get(void ** ptr, size_t bytes);
 
+/* One round of a batch call over a geometry with paged tiles: which items to
+ * run (ids / n_in, NULL for all of 0 .. n-1) and where to list the ones that
+ * met a tile that is not resident (faulted / n_faulted) and, over the tile
+ * table, how much each tile is wanted.  All NULL: nothing is paged. */
+struct tamd_paging {
+        const int * ids;
+        const unsigned long long * n_in;
+        int * faulted;
+        unsigned long long * n_faulted;
+        unsigned * wanted;       /* per entry of the tile table: how many listed items want it */
+        unsigned * wanted_first; /* bitmap: wanted by the first item of the list (served without fail) */
+        double * tentative;      /* traces: per ray, the step a waiting ray was about to take */
+        int first_id;            /* the item whose wants go to wanted_first (-1: the first listed) */
+};
+
 /* Kernel launchers.  All pointers are DEVICE pointers; NULL output pointers
  * are allowed where the public API allows them. */
 int tamd_k_ecef_from_geodetic(long n, const double * lat, const double * lon,
@@ -143,25 +162,25 @@ int tamd_k_ecef_to_horizontal(long n, const double * lat, const double * lon,
     const double * dir, double * az, double * el);
 /* elevation of n points on metas[0] of the view (a MAP or a STACK entry) */
 int tamd_k_elevation(struct tamd_view view, long n, const double * a,
-    const double * b, double * z, int * inside);
+    const double * b, double * z, int * inside, struct tamd_paging pg);
 /* gradient of n points on metas[0]: MAP (x, y) -> (gx, gy); STACK (lat, lon)
  * -> (glat, glon); ga/gb are in-out */
 int tamd_k_gradient(struct tamd_view view, long n, const double * a,
-    const double * b, double * ga, double * gb, int * inside);
+    const double * b, double * ga, double * gb, int * inside, struct tamd_paging pg);
 int tamd_k_position(struct tamd_view view, long n, const double * lat,
     const double * lon, const double * height, int layer, double * pos,
-    int * data_index);
+    int * data_index, struct tamd_paging pg);
 int tamd_k_step(struct tamd_view view, long n, double * pos,
     const double * dir, double * lat, double * lon, double * alt,
-    double * elev, double * step, int * index, int flags);
+    double * elev, double * step, int * index, int flags, struct tamd_paging pg);
 /* stats: 4 x uint64 on the device (rays, steps, samples, capped); queue: 3 x
  * uint64 (work counters of the two phases, number of parked rays); both zeroed
  * by the launcher.  parked: int[n] scratch for the ids of rays handed to the
  * second phase, or NULL for a single-phase launch. */
 int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length,
-    int * n_steps, int flags, int * parked, unsigned long long * stats,
-    unsigned long long * queue);
+    int * n_steps, int flags, int * parked, struct tamd_paging pg,
+    unsigned long long * stats, unsigned long long * queue);
 /* n single steps with a direction: the step kernel lists the rays that crossed
  * a boundary (cross_ray / cross_ds: scratch for n entries each, or NULL to
  * bisect in place) and a second kernel bisects them, packed; `flags` are enum
@@ -169,7 +188,8 @@ int tamd_k_trace(struct tamd_view view, long n, double * pos,
 int tamd_k_step_dir(struct tamd_view view, long n, double * pos,
     const double * dir, double * lat, double * lon, double * alt,
     double * elev, double * step, int * index, int flags, int * cross_ray,
-    double * cross_ds, unsigned long long * stats, unsigned long long * queue);
+    double * cross_ds, struct tamd_paging pg, unsigned long long * stats,
+    unsigned long long * queue);
 int tamd_k_philox(long n, unsigned long long seed, unsigned long long stream,
     long first, unsigned * out);
 int tamd_k_isotropic(long n, unsigned long long seed, unsigned long long stream,

@@ -301,7 +301,10 @@ static int map_elevation_n(struct turtle_map * map, long n, const double * x,
             tamd_stage_out(&st, elevation, nb, &dz) ||
             tamd_stage_out(&st, inside, n * sizeof(int), &di))
                 return 1;
-        if (tamd_k_elevation(view, n, dx, dy, dz, di)) return 1;
+        {
+                const struct tamd_paging none = { NULL, NULL, NULL, NULL, NULL, NULL, NULL, -1 };
+                if (tamd_k_elevation(view, n, dx, dy, dz, di, none)) return 1;
+        }
         if (tamd_stage_fetch(&st, elevation, nb, dz) ||
             tamd_stage_fetch(&st, inside, n * sizeof(int), di))
                 return 1;
@@ -355,7 +358,10 @@ static int map_gradient_n(struct turtle_map * map, long n, const double * x,
             tamd_stage_in(&st, gx, nb, &dgx) || tamd_stage_in(&st, gy, nb, &dgy) ||
             tamd_stage_out(&st, inside, n * sizeof(int), &di))
                 return 1;
-        if (tamd_k_gradient(view, n, dx, dy, dgx, dgy, di)) return 1;
+        {
+                const struct tamd_paging none = { NULL, NULL, NULL, NULL, NULL, NULL, NULL, -1 };
+                if (tamd_k_gradient(view, n, dx, dy, dgx, dgy, di, none)) return 1;
+        }
         if (tamd_stage_fetch(&st, gx, nb, dgx) || tamd_stage_fetch(&st, gy, nb, dgy) ||
             tamd_stage_fetch(&st, inside, n * sizeof(int), di))
                 return 1;

@@ -120,11 +120,13 @@ enum turtle_return turtle_stack_create(struct turtle_stack ** stack,
                 s->root = strdup(path);
                 s->path = calloc(slots ? slots : 1, sizeof(*s->path));
                 s->tile = calloc(slots ? slots : 1, sizeof(*s->tile));
+                s->stamp = calloc(slots ? slots : 1, sizeof(*s->stamp));
         }
-        if ((s == NULL) || (s->root == NULL) || (s->path == NULL) || (s->tile == NULL)) {
+        if ((s == NULL) || (s->root == NULL) || (s->path == NULL) || (s->tile == NULL) ||
+            (s->stamp == NULL)) {
                 closedir(dir);
                 if (s != NULL) {
-                        free(s->root), free(s->path), free(s->tile);
+                        free(s->root), free(s->path), free(s->tile), free(s->stamp);
                         free(s);
                 }
                 return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
@@ -147,6 +149,7 @@ enum turtle_return turtle_stack_create(struct turtle_stack ** stack,
                 const int ix = (int)((meta.x0 - long_min) / long_delta);
                 const int iy = (int)((meta.y0 - lat_min) / lat_delta);
                 const size_t i = (size_t)iy * long_n + ix;
+                if (s->path[i] == NULL) s->n_files++;
                 free(s->path[i]);
                 s->path[i] = strdup(file);
         }
@@ -179,7 +182,8 @@ void turtle_stack_destroy(struct turtle_stack ** stack)
         const int n = s->latitude_n * s->longitude_n;
         int i;
         for (i = 0; i < n; i++) free(s->path[i]);
-        free(s->path), free(s->tile), free(s->root);
+        free(s->path), free(s->tile), free(s->stamp), free(s->root);
+        tamd_dev_free(s->d_tables);
         free(s);
         *stack = NULL;
 }
@@ -196,38 +200,114 @@ enum turtle_return turtle_stack_clear(struct turtle_stack * stack)
         return TURTLE_RETURN_SUCCESS;
 }
 
-int tamd_stack_load_all(struct turtle_stack * s, char * message, size_t size)
+/* never below 16: a lookup near a seam consults the boxes of the 3 x 3 tiles
+ * around it, and a ray's step (the bisection of a crossing) can need two such
+ * neighbourhoods, side by side, resident together */
+int tamd_stack_budget(const struct turtle_stack * s)
 {
-        const int n = s->latitude_n * s->longitude_n;
+        if (s->max_size <= 0) return INT_MAX;
+        return (s->max_size < TAMD_STACK_FLOOR) ? TAMD_STACK_FLOOR : s->max_size;
+}
+
+int turtle_amd_stack_resident(const struct turtle_stack * stack) { return stack->n_loaded; }
+
+int tamd_stack_is_paged(const struct turtle_stack * s) { return s->n_loaded < s->n_files; }
+
+/* one tile from its file into memory (it goes on to HBM at the next device call) */
+static int stack_load_tile(struct turtle_stack * s, int i, char * message, size_t size)
+{
+        struct turtle_map * m = calloc(1, sizeof(*m));
+        int rc = (m == NULL) ? TURTLE_RETURN_MEMORY_ERROR : tile_probe(s->path[i], m);
+        if (rc == TURTLE_RETURN_SUCCESS) {
+                m->nodes = malloc((size_t)m->nx * m->ny * sizeof(*m->nodes));
+                rc = (m->nodes == NULL) ? TURTLE_RETURN_MEMORY_ERROR : tile_read(s->path[i], m);
+        }
+        if (rc != TURTLE_RETURN_SUCCESS) {
+                if (m != NULL) free(m->nodes);
+                free(m);
+                if (rc > N_TURTLE_RETURNS) rc = TURTLE_RETURN_BAD_FORMAT;
+                snprintf(message, size, "could not load tile `%s'", s->path[i]);
+                return rc;
+        }
+        m->stack = s;
+        m->d_stale = 1;
+        s->tile[i] = m;
+        s->stamp[i] = ++s->clock;
+        s->n_loaded++;
+        tamd_geometry_epoch++;
+        return TURTLE_RETURN_SUCCESS;
+}
+
+static void stack_drop_tile(struct turtle_stack * s, int i)
+{
+        struct turtle_map * m = s->tile[i];
+        m->stack = NULL; /* do not walk back into the table */
+        turtle_map_destroy(&m);
+        s->tile[i] = NULL;
+        s->n_loaded--;
+        tamd_geometry_epoch++;
+}
+
+int tamd_stack_preload(struct turtle_stack * s, char * message, size_t size)
+{
+        const int n = s->latitude_n * s->longitude_n, budget = tamd_stack_budget(s);
         int i;
-        for (i = 0; i < n; i++) {
+        for (i = 0; (i < n) && (s->n_loaded < budget); i++) {
                 if ((s->path[i] == NULL) || (s->tile[i] != NULL)) continue;
-                struct turtle_map * m = calloc(1, sizeof(*m));
-                int rc = (m == NULL) ? TURTLE_RETURN_MEMORY_ERROR :
-                                       tile_probe(s->path[i], m);
-                if (rc == TURTLE_RETURN_SUCCESS) {
-                        m->nodes = malloc((size_t)m->nx * m->ny * sizeof(*m->nodes));
-                        rc = (m->nodes == NULL) ? TURTLE_RETURN_MEMORY_ERROR :
-                                                  tile_read(s->path[i], m);
-                }
-                if (rc != TURTLE_RETURN_SUCCESS) {
-                        if (m != NULL) free(m->nodes);
-                        free(m);
-                        if (rc > N_TURTLE_RETURNS) rc = TURTLE_RETURN_BAD_FORMAT;
-                        snprintf(message, size, "could not load tile `%s'", s->path[i]);
-                        return rc;
-                }
-                m->stack = s;
-                m->d_stale = 1;
-                s->tile[i] = m;
-                s->n_loaded++;
-                tamd_geometry_epoch++;
+                const int rc = stack_load_tile(s, i, message, size);
+                if (rc != TURTLE_RETURN_SUCCESS) return rc;
         }
         return TURTLE_RETURN_SUCCESS;
 }
 
-/* [ref stack.c:257-297]: bring the tiles into memory (here: every tile, and
- * they go on to HBM at the next device call) */
+int tamd_stack_page_in(struct turtle_stack * s, const unsigned * wanted,
+    const unsigned * wanted_first, int first_bit, char * message, size_t size)
+{
+        const int n = s->latitude_n * s->longitude_n, budget = tamd_stack_budget(s);
+        int i, loaded = 0;
+#define FIRST(i) ((wanted_first[((i) + first_bit) >> 5] >> (((i) + first_bit) & 31)) & 1u)
+#define DEMAND(i) (wanted[(i) + first_bit])
+        /* the resident tiles this round wanted are the most recently used */
+        for (i = 0; i < n; i++)
+                if (DEMAND(i) && (s->tile[i] != NULL)) s->stamp[i] = ++s->clock;
+        for (;;) {
+                /* the next tile to bring in: one of the first item's, else the one
+                 * in most demand */
+                int want = -1, first = 0;
+                for (i = 0; i < n; i++) {
+                        if ((s->tile[i] != NULL) || (s->path[i] == NULL) || !DEMAND(i)) continue;
+                        if (FIRST(i)) {
+                                want = i, first = 1;
+                                break;
+                        }
+                        if ((want < 0) || (DEMAND(i) > DEMAND(want))) want = i;
+                }
+                if (want < 0) break;
+                if (s->n_loaded >= budget) {
+                        /* who goes: the tile in least demand, the least recently
+                         * wanted of those; never one of the first item's */
+                        int out = -1;
+                        for (i = 0; i < n; i++) {
+                                if ((s->tile[i] == NULL) || FIRST(i)) continue;
+                                if ((out < 0) || (DEMAND(i) < DEMAND(out)) ||
+                                    ((DEMAND(i) == DEMAND(out)) && (s->stamp[i] < s->stamp[out])))
+                                        out = i;
+                        }
+                        /* ... and only for a tile in more demand (or the first item's) */
+                        if ((out < 0) || (!first && (DEMAND(out) >= DEMAND(want)))) break;
+                        stack_drop_tile(s, out);
+                }
+                const int rc = stack_load_tile(s, want, message, size);
+                if (rc != TURTLE_RETURN_SUCCESS) return -rc;
+                loaded++;
+        }
+#undef FIRST
+#undef DEMAND
+        return loaded;
+}
+
+/* [ref stack.c:257-297]: bring tiles into memory, in directory order, until the
+ * stack is full (they go on to HBM at the next device call) */
 enum turtle_return turtle_stack_load(struct turtle_stack * stack)
 {
         TAMD_ERROR_INIT(&turtle_stack_load);
@@ -236,7 +316,7 @@ enum turtle_return turtle_stack_load(struct turtle_stack * stack)
         if ((stack->lock != NULL) && (stack->lock() != 0))
                 return TAMD_RAISE(TURTLE_RETURN_LOCK_ERROR, "could not acquire the lock");
         char message[4200];
-        const int rc = tamd_stack_load_all(stack, message, sizeof(message));
+        const int rc = tamd_stack_preload(stack, message, sizeof(message));
         if ((stack->unlock != NULL) && (stack->unlock() != 0))
                 return TAMD_RAISE(TURTLE_RETURN_UNLOCK_ERROR, "could not release the lock");
         if (rc != TURTLE_RETURN_SUCCESS)
@@ -244,13 +324,16 @@ enum turtle_return turtle_stack_load(struct turtle_stack * stack)
         return TURTLE_RETURN_SUCCESS;
 }
 
-/* One-stack view for the elevation kernel.  Returns 0, -1 on a device error,
- * or a positive enum turtle_return with `message` set. */
+/* One-stack view for the elevation / gradient kernels, in a device block the
+ * stack keeps (rebuilt when tiles came or went).  Returns 0, -1 on a device
+ * error, or a positive enum turtle_return with `message` set. */
 static int stack_view(struct turtle_stack * s, struct tamd_view * view, char * message,
     size_t size)
 {
-        int rc = tamd_stack_load_all(s, message, size);
-        if (rc != TURTLE_RETURN_SUCCESS) return rc;
+        if ((s->d_tables != NULL) && (s->view_epoch == tamd_geometry_epoch)) {
+                *view = s->view;
+                return 0;
+        }
         const int slots = s->latitude_n * s->longitude_n;
         const size_t bytes = sizeof(struct tamd_stack) + sizeof(struct tamd_meta) +
             (size_t)(slots + 1) * (sizeof(int) + sizeof(struct tamd_grid));
@@ -265,7 +348,7 @@ static int stack_view(struct turtle_stack * s, struct tamd_view * view, char * m
         int * tiles = (int *)(meta + 1);
         int i, n_grids = 0;
         for (i = 0; i < slots; i++) {
-                tiles[i] = -1;
+                tiles[i] = (s->path[i] != NULL) ? TAMD_TILE_PAGED : TAMD_TILE_NONE;
                 if (s->tile[i] == NULL) continue;
                 if (tamd_map_sync(s->tile[i], &grids[n_grids])) {
                         free(host);
@@ -278,20 +361,86 @@ static int stack_view(struct turtle_stack * s, struct tamd_view * view, char * m
         st->nlat = s->latitude_n, st->nlon = s->longitude_n;
         st->tile_first = 0;
         meta->kind = TAMD_STACK;
-        void * dev;
-        if (tamd_scratch_get(&dev, bytes) || tamd_dev_h2d(dev, host, bytes)) {
+        if (bytes > s->d_tables_size) {
+                tamd_dev_sync();
+                tamd_dev_free(s->d_tables);
+                s->d_tables = NULL, s->d_tables_size = 0;
+                if (tamd_dev_malloc(&s->d_tables, bytes)) {
+                        free(host);
+                        return -1;
+                }
+                s->d_tables_size = bytes;
+        }
+        if (tamd_dev_h2d(s->d_tables, host, bytes)) {
                 free(host);
                 return -1;
         }
-        memset(view, 0, sizeof(*view));
-        view->grids = (const struct tamd_grid *)dev;
-        view->stacks = (const struct tamd_stack *)((char *)dev + ((char *)st - host));
-        view->metas = (const struct tamd_meta *)((char *)dev + ((char *)meta - host));
-        view->tiles = (const int *)((char *)dev + ((char *)tiles - host));
-        view->n_layers = 1;
-        view->geoid = -1;
+        char * dev = s->d_tables;
+        memset(&s->view, 0, sizeof(s->view));
+        s->view.grids = (const struct tamd_grid *)dev;
+        s->view.stacks = (const struct tamd_stack *)(dev + ((char *)st - host));
+        s->view.metas = (const struct tamd_meta *)(dev + ((char *)meta - host));
+        s->view.tiles = (const int *)(dev + ((char *)tiles - host));
+        s->view.n_layers = 1;
+        s->view.geoid = -1;
+        s->view_epoch = tamd_geometry_epoch;
+        *view = s->view;
         free(host);
         return 0;
+}
+
+/* The rounds of a batch call on one stack (paging.c): `launch` runs the kernel
+ * of a round.  Returns 0, -1 (device) or a positive enum turtle_return. */
+struct stack_call {
+        struct turtle_stack * stack;
+        long n;
+        void *a, *b, *c, *d, *e;
+        int gradient;
+};
+
+static int stack_rounds(struct stack_call * call, char * message, size_t size)
+{
+        struct turtle_stack * s = call->stack;
+        struct tamd_pager pager;
+        memset(&pager, 0, sizeof(pager));
+        if (tamd_stack_is_paged(s) &&
+            tamd_pager_begin(&pager, call->n, s->latitude_n * s->longitude_n))
+                return -1;
+        int rc = 0;
+        for (;;) {
+                struct tamd_view view;
+                struct tamd_paging pg;
+                if ((rc = stack_view(s, &view, message, size)) != 0) break;
+                if (tamd_pager_round(&pager, &pg)) {
+                        rc = -1;
+                        break;
+                }
+                if (call->gradient ?
+                        tamd_k_gradient(view, call->n, call->a, call->b, call->c, call->d, call->e, pg) :
+                        tamd_k_elevation(view, call->n, call->a, call->b, call->c, call->e, pg)) {
+                        rc = -1;
+                        break;
+                }
+                unsigned long long faulted = 0;
+                if (tamd_pager_collect(&pager, &faulted)) {
+                        rc = -1;
+                        break;
+                }
+                if (faulted == 0) break;
+                const int got = tamd_stack_page_in(s, pager.wanted, pager.pinned, 0, message, size);
+                if (got < 0) {
+                        rc = -got;
+                        break;
+                }
+                if (pager.rounds > TAMD_PAGING_ROUNDS) { /* cannot be: a round serves an item */
+                        snprintf(message, size, "stack of %d tiles is too small for this query (%s)",
+                            tamd_stack_budget(s), s->root);
+                        rc = TURTLE_RETURN_MEMORY_ERROR;
+                        break;
+                }
+        }
+        tamd_pager_end(&pager);
+        return rc;
 }
 
 static int stack_elevation_n(struct turtle_stack * stack, long n,
@@ -299,25 +448,16 @@ static int stack_elevation_n(struct turtle_stack * stack, long n,
     int * inside, int space, char * message, size_t size)
 {
         struct tamd_stage st;
-        struct tamd_view view;
         void *da, *db, *dz, *di;
         const size_t nb = (size_t)n * sizeof(double);
-        const size_t tables =
-            (size_t)(stack->latitude_n * stack->longitude_n + 2) * 128 + 4096;
-        if (tamd_stage_begin(&st, space, 3 * nb + n * sizeof(int) + tables)) return -1;
-        if (space == TURTLE_AMD_DEVICE) {
-                void * all;
-                tamd_scratch_reset();
-                if (tamd_scratch_get(&all, tables)) return -1;
-                tamd_scratch_reset();
-        }
-        const int rc = stack_view(stack, &view, message, size);
-        if (rc != 0) return rc;
+        if (tamd_stage_begin(&st, space, 3 * nb + n * sizeof(int))) return -1;
         if (tamd_stage_in(&st, latitude, nb, &da) || tamd_stage_in(&st, longitude, nb, &db) ||
             tamd_stage_out(&st, elevation, nb, &dz) ||
             tamd_stage_out(&st, inside, n * sizeof(int), &di))
                 return -1;
-        if (tamd_k_elevation(view, n, da, db, dz, di)) return -1;
+        struct stack_call call = { stack, n, da, db, dz, NULL, di, 0 };
+        const int rc = stack_rounds(&call, message, size);
+        if (rc != 0) return rc;
         if (tamd_stage_fetch(&st, elevation, nb, dz) ||
             tamd_stage_fetch(&st, inside, n * sizeof(int), di))
                 return -1;
@@ -377,25 +517,16 @@ static int stack_gradient_n(struct turtle_stack * stack, long n, const double * 
     char * message, size_t size)
 {
         struct tamd_stage st;
-        struct tamd_view view;
         void *da, *db, *dga, *dgb, *di;
         const size_t nb = (size_t)n * sizeof(double);
-        const size_t tables =
-            (size_t)(stack->latitude_n * stack->longitude_n + 2) * 128 + 4096;
-        if (tamd_stage_begin(&st, space, 4 * nb + n * sizeof(int) + tables)) return -1;
-        if (space == TURTLE_AMD_DEVICE) {
-                void * all;
-                tamd_scratch_reset();
-                if (tamd_scratch_get(&all, tables)) return -1;
-                tamd_scratch_reset();
-        }
-        const int rc = stack_view(stack, &view, message, size);
-        if (rc != 0) return rc;
+        if (tamd_stage_begin(&st, space, 4 * nb + n * sizeof(int))) return -1;
         if (tamd_stage_in(&st, latitude, nb, &da) || tamd_stage_in(&st, longitude, nb, &db) ||
             tamd_stage_in(&st, glat, nb, &dga) || tamd_stage_in(&st, glon, nb, &dgb) ||
             tamd_stage_out(&st, inside, n * sizeof(int), &di))
                 return -1;
-        if (tamd_k_gradient(view, n, da, db, dga, dgb, di)) return -1;
+        struct stack_call call = { stack, n, da, db, dga, dgb, di, 1 };
+        const int rc = stack_rounds(&call, message, size);
+        if (rc != 0) return rc;
         if (tamd_stage_fetch(&st, glat, nb, dga) || tamd_stage_fetch(&st, glon, nb, dgb) ||
             tamd_stage_fetch(&st, inside, n * sizeof(int), di))
                 return -1;

@@ -247,15 +247,15 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
         s->view.resolution = s->resolution_factor;
         if ((s->epoch == tamd_geometry_epoch) && (s->d_tables != NULL)) return 0;
 
-        /* make sure every tile of every stack is in memory */
+        /* the tiles that are in memory go into the tables; the others read
+         * TAMD_TILE_PAGED there and come in when a batch wants them (paging.c) */
         int i, j, n_stacks = 0, n_tiles = 0, n_metas = 0;
         for (i = 0; i < s->n_data; i++) {
                 if (s->data[i].kind != TAMD_STACK) continue;
-                const int rc = tamd_stack_load_all(s->data[i].stack, message, size);
-                if (rc != TURTLE_RETURN_SUCCESS) return rc;
                 n_stacks++;
                 n_tiles += s->data[i].stack->latitude_n * s->data[i].stack->longitude_n;
         }
+        s->n_table = n_tiles;
         for (i = 0; i < s->n_layers; i++) n_metas += s->layers[i].size;
 
         /* unique grids: maps, tiles, geoid */
@@ -280,7 +280,7 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
                         t->tile_first = tile_count;
                         const int slots = st->latitude_n * st->longitude_n;
                         for (j = 0; (rc == 0) && (j < slots); j++) {
-                                int g = -1;
+                                int g = (st->path[j] != NULL) ? TAMD_TILE_PAGED : TAMD_TILE_NONE;
                                 if (st->tile[j] != NULL) {
                                         g = grid_index(&gl, st->tile[j]);
                                         if (g < 0) rc = 1;
@@ -400,6 +400,84 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
         return dev_fail ? -1 : 0;
 }
 
+/* ---- batch calls over paged stacks (paging.c) --------------------------- */
+
+static int stepper_is_paged(const struct turtle_stepper * s)
+{
+        int i;
+        for (i = 0; i < s->n_data; i++)
+                if ((s->data[i].kind == TAMD_STACK) && tamd_stack_is_paged(s->data[i].stack)) return 1;
+        return 0;
+}
+
+/* the tiles a round wanted, stack by stack (the tile table lists the stacks in
+ * the order of s->data): 0 if none could come in, -1 with `code` set on error */
+static int stepper_page_in(struct turtle_stepper * s, const unsigned * wanted,
+    const unsigned * wanted_first, int * code, char * message, size_t size)
+{
+        int i, first = 0, loaded = 0;
+        for (i = 0; i < s->n_data; i++) {
+                if (s->data[i].kind != TAMD_STACK) continue;
+                struct turtle_stack * st = s->data[i].stack;
+                const int got = tamd_stack_page_in(st, wanted, wanted_first, first, message, size);
+                if (got < 0) {
+                        *code = -got;
+                        return -1;
+                }
+                loaded += got;
+                first += st->latitude_n * st->longitude_n;
+        }
+        return loaded;
+}
+
+/* Runs `launch` (the kernels of one round) until nothing is listed any more.
+ * Returns an enum turtle_return; TURTLE_RETURN_LIBRARY_ERROR: device failure
+ * (message empty) */
+typedef int stepper_round_t(struct turtle_stepper * stepper, struct tamd_paging pg, int round,
+    void * args);
+
+static int stepper_rounds(struct turtle_stepper * stepper, long n, stepper_round_t * launch,
+    void * args, char * message, size_t size)
+{
+        struct tamd_pager pager;
+        memset(&pager, 0, sizeof(pager));
+        message[0] = 0;
+        int rc = tamd_stepper_flatten(stepper, message, size);
+        if (rc != 0) return (rc < 0) ? TURTLE_RETURN_LIBRARY_ERROR : rc;
+        if (stepper_is_paged(stepper) && tamd_pager_begin(&pager, n, stepper->n_table))
+                return TURTLE_RETURN_LIBRARY_ERROR;
+        for (;;) {
+                struct tamd_paging pg;
+                rc = tamd_stepper_flatten(stepper, message, size);
+                if (rc != 0) {
+                        rc = (rc < 0) ? TURTLE_RETURN_LIBRARY_ERROR : rc;
+                        break;
+                }
+                unsigned long long faulted = 0;
+                if (tamd_pager_round(&pager, &pg) || launch(stepper, pg, pager.rounds, args) ||
+                    tamd_pager_collect(&pager, &faulted)) {
+                        rc = TURTLE_RETURN_LIBRARY_ERROR;
+                        break;
+                }
+                if (faulted == 0) break;
+                int code = 0;
+                const int got = stepper_page_in(stepper, pager.wanted, pager.pinned, &code,
+                    message, size);
+                if (got < 0) {
+                        rc = code;
+                        break;
+                }
+                if (pager.rounds > TAMD_PAGING_ROUNDS) { /* cannot be: a round serves an item */
+                        snprintf(message, size,
+                            "the stacks of the stepper are too small (stack_size) for this batch");
+                        rc = TURTLE_RETURN_MEMORY_ERROR;
+                        break;
+                }
+        }
+        tamd_pager_end(&pager);
+        return rc;
+}
+
 #define FLATTEN_OR_RETURN(stepper)                                             \
         do {                                                                   \
                 char message_[4200];                                           \
@@ -410,6 +488,21 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
 
 /* ---- batch entry points --------------------------------------------------- */
 
+struct position_args {
+        long n;
+        void *lat, *lon, *height;
+        int layer;
+        void *pos, *index;
+};
+
+static int position_round(struct turtle_stepper * stepper, struct tamd_paging pg, int round, void * p)
+{
+        struct position_args * a = p;
+        (void)round;
+        return tamd_k_position(stepper->view, a->n, a->lat, a->lon, a->height, a->layer, a->pos,
+            a->index, pg);
+}
+
 enum turtle_return turtle_stepper_position_n(struct turtle_stepper * stepper, long n,
     const double * latitude, const double * longitude, const double * height,
     int layer_index, double * position, int * data_index, int space)
@@ -419,18 +512,22 @@ enum turtle_return turtle_stepper_position_n(struct turtle_stepper * stepper, lo
                 return TAMD_RAISE(TURTLE_RETURN_DOMAIN_ERROR, "no valid data");
         if ((position == NULL) || (data_index == NULL))
                 return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
-        FLATTEN_OR_RETURN(stepper);
         struct tamd_stage st;
-        void *dla, *dlo, *dh, *dp, *di;
+        struct position_args args = { n, NULL, NULL, NULL, layer_index, NULL, NULL };
         const size_t nb = (size_t)n * sizeof(double);
         if (tamd_stage_begin(&st, space, 6 * nb + n * sizeof(int)) ||
-            tamd_stage_in(&st, latitude, nb, &dla) || tamd_stage_in(&st, longitude, nb, &dlo) ||
-            tamd_stage_in(&st, height, nb, &dh) ||
-            tamd_stage_in(&st, position, 3 * nb, &dp) || /* untouched rows keep their value */
-            tamd_stage_out(&st, data_index, n * sizeof(int), &di) ||
-            tamd_k_position(stepper->view, n, dla, dlo, dh, layer_index, dp, di) ||
-            tamd_stage_fetch(&st, position, 3 * nb, dp) ||
-            tamd_stage_fetch(&st, data_index, n * sizeof(int), di) || tamd_stage_end(&st))
+            tamd_stage_in(&st, latitude, nb, &args.lat) ||
+            tamd_stage_in(&st, longitude, nb, &args.lon) ||
+            tamd_stage_in(&st, height, nb, &args.height) ||
+            tamd_stage_in(&st, position, 3 * nb, &args.pos) || /* untouched rows keep their value */
+            tamd_stage_out(&st, data_index, n * sizeof(int), &args.index))
+                return TAMD_RAISE_DEVICE();
+        char message[4200];
+        const int rc = stepper_rounds(stepper, n, &position_round, &args, message, sizeof(message));
+        if (rc == TURTLE_RETURN_LIBRARY_ERROR) return TAMD_RAISE_DEVICE();
+        if (rc != 0) return TAMD_RAISE((enum turtle_return)rc, "%s", message);
+        if (tamd_stage_fetch(&st, position, 3 * nb, args.pos) ||
+            tamd_stage_fetch(&st, data_index, n * sizeof(int), args.index) || tamd_stage_end(&st))
                 return TAMD_RAISE_DEVICE();
         return TURTLE_RETURN_SUCCESS;
 }
@@ -459,6 +556,24 @@ static int tamd_stepper_scratch(struct turtle_stepper * stepper, long n)
         return 0;
 }
 
+struct step_args {
+        long n;
+        void *pos, *dir, *lat, *lon, *alt, *elev, *step, *index;
+        int flags, listed;
+};
+
+static int step_round(struct turtle_stepper * stepper, struct tamd_paging pg, int round, void * p)
+{
+        struct step_args * a = p;
+        (void)round;
+        if (a->dir == NULL)
+                return tamd_k_step(stepper->view, a->n, a->pos, a->dir, a->lat, a->lon, a->alt,
+                    a->elev, a->step, a->index, a->flags, pg);
+        return tamd_k_step_dir(stepper->view, a->n, a->pos, a->dir, a->lat, a->lon, a->alt, a->elev,
+            a->step, a->index, a->flags, a->listed ? stepper->d_parked : NULL,
+            a->listed ? stepper->d_scratch_ds : NULL, pg, stepper->d_stats, stepper->d_stats + 4);
+}
+
 static enum turtle_return step_n(struct tamd_error * error, struct turtle_stepper * stepper,
     long n, double * position, const double * direction, double * latitude,
     double * longitude, double * altitude, double * elevation, double * step, int * index,
@@ -470,7 +585,6 @@ static enum turtle_return step_n(struct tamd_error * error, struct turtle_steppe
         if ((flags & TURTLE_AMD_STEP_RESUME) && ((altitude == NULL) || (elevation == NULL)))
                 return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS,
                     "TURTLE_AMD_STEP_RESUME needs altitude, elevation and index");
-        FLATTEN_OR_RETURN(stepper);
         struct tamd_stage st;
         void *dp, *dd, *dla, *dlo, *dal, *del, *dst, *dix;
         const size_t nb = (size_t)n * sizeof(double);
@@ -498,15 +612,13 @@ static enum turtle_return step_n(struct tamd_error * error, struct turtle_steppe
          * boundary (a single step bisects in place: nothing to pack) */
         const int listed = (direction != NULL) && (n > 1) && (tamd_stepper_scratch(stepper, n) == 0);
         if ((direction != NULL) && (n > 1) && !listed && (stepper->parked_capacity < 0)) bad = 1;
-        if (bad ||
-            ((direction != NULL) ?
-                    tamd_k_step_dir(stepper->view, n, dp, dd, dla, dlo, dal, del, dst, dix,
-                        flags, listed ? stepper->d_parked : NULL,
-                        listed ? stepper->d_scratch_ds : NULL, stepper->d_stats,
-                        stepper->d_stats + 4) :
-                    tamd_k_step(stepper->view, n, dp, dd, dla, dlo, dal, del, dst, dix,
-                        flags)) ||
-            ((direction != NULL) && tamd_stage_fetch(&st, position, 3 * nb, dp)) ||
+        if (bad) return TAMD_RAISE_DEVICE();
+        struct step_args args = { n, dp, dd, dla, dlo, dal, del, dst, dix, flags, listed };
+        char message[4200];
+        const int rc = stepper_rounds(stepper, n, &step_round, &args, message, sizeof(message));
+        if (rc == TURTLE_RETURN_LIBRARY_ERROR) return TAMD_RAISE_DEVICE();
+        if (rc != 0) return TAMD_RAISE((enum turtle_return)rc, "%s", message);
+        if (((direction != NULL) && tamd_stage_fetch(&st, position, 3 * nb, dp)) ||
             tamd_stage_fetch(&st, latitude, nb, dla) ||
             tamd_stage_fetch(&st, longitude, nb, dlo) ||
             tamd_stage_fetch(&st, altitude, nb, dal) ||
@@ -527,6 +639,22 @@ enum turtle_return turtle_stepper_step_n(struct turtle_stepper * stepper, long n
             altitude, elevation, step, index, flags, space);
 }
 
+struct trace_args {
+        long n;
+        void *pos, *dir, *index, *length, *n_steps;
+        int max_steps, flags, scratch;
+};
+
+static int trace_round(struct turtle_stepper * stepper, struct tamd_paging pg, int round, void * p)
+{
+        struct trace_args * a = p;
+        (void)round;
+        pg.tentative = a->scratch ? stepper->d_scratch_ds : NULL;
+        return tamd_k_trace(stepper->view, a->n, a->pos, a->dir, a->max_steps, a->index, a->length,
+            a->n_steps, a->flags, a->scratch ? stepper->d_parked : NULL, pg, stepper->d_stats,
+            stepper->d_stats + 4);
+}
+
 enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long n,
     double * position, const double * direction, int max_steps, int * index,
     double * length, int * n_steps, int flags, int space)
@@ -534,27 +662,37 @@ enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long 
         TAMD_ERROR_INIT(&turtle_stepper_trace_n);
         if ((position == NULL) || (direction == NULL) || (index == NULL))
                 return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
-        FLATTEN_OR_RETURN(stepper);
-        const int scratch = (tamd_stepper_scratch(stepper, n) == 0);
-        if (!scratch && (stepper->parked_capacity < 0)) return TAMD_RAISE_DEVICE();
+        struct trace_args args = { n, NULL, NULL, NULL, NULL, NULL, max_steps, flags, 0 };
+        args.scratch = (tamd_stepper_scratch(stepper, n) == 0);
+        if (!args.scratch && (stepper->parked_capacity < 0)) return TAMD_RAISE_DEVICE();
         struct tamd_stage st;
-        void *dp, *dd, *dix, *dlen, *dns;
         const size_t nb = (size_t)n * sizeof(double);
         if (tamd_stage_begin(&st, space, 7 * nb + 3 * n * sizeof(int)) ||
-            tamd_stage_in(&st, position, 3 * nb, &dp) ||
-            tamd_stage_in(&st, direction, 3 * nb, &dd) ||
+            tamd_stage_in(&st, position, 3 * nb, &args.pos) ||
+            tamd_stage_in(&st, direction, 3 * nb, &args.dir) ||
             ((flags & TURTLE_AMD_TRACE_RESUME) ?
-                    tamd_stage_in(&st, index, 2 * n * sizeof(int), &dix) :
-                    tamd_stage_out(&st, index, 2 * n * sizeof(int), &dix)) ||
-            tamd_stage_out(&st, length, nb, &dlen) ||
-            tamd_stage_out(&st, n_steps, n * sizeof(int), &dns) ||
-            tamd_k_trace(stepper->view, n, dp, dd, max_steps, dix, dlen, dns, flags,
-                scratch ? stepper->d_parked : NULL, stepper->d_stats,
-                stepper->d_stats + 4) ||
-            tamd_stage_fetch(&st, position, 3 * nb, dp) ||
-            tamd_stage_fetch(&st, index, 2 * n * sizeof(int), dix) ||
-            tamd_stage_fetch(&st, length, nb, dlen) ||
-            tamd_stage_fetch(&st, n_steps, n * sizeof(int), dns) || tamd_stage_end(&st))
+                    tamd_stage_in(&st, index, 2 * n * sizeof(int), &args.index) :
+                    tamd_stage_out(&st, index, 2 * n * sizeof(int), &args.index)) ||
+            tamd_stage_out(&st, length, nb, &args.length) ||
+            tamd_stage_out(&st, n_steps, n * sizeof(int), &args.n_steps))
+                return TAMD_RAISE_DEVICE();
+        /* a ray that waits for a tile keeps its path length and step count in
+         * these arrays: over paged stacks they exist even if the caller has none */
+        if (stepper_is_paged(stepper) && !args.scratch)
+                return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR,
+                    "a batch this large cannot run over stacks with tiles left to page in");
+        if (stepper_is_paged(stepper) && (n > 0) &&
+            (((args.length == NULL) && tamd_scratch_get(&args.length, nb)) ||
+                ((args.n_steps == NULL) && tamd_scratch_get(&args.n_steps, n * sizeof(int)))))
+                return TAMD_RAISE_DEVICE();
+        char message[4200];
+        const int rc = stepper_rounds(stepper, n, &trace_round, &args, message, sizeof(message));
+        if (rc == TURTLE_RETURN_LIBRARY_ERROR) return TAMD_RAISE_DEVICE();
+        if (rc != 0) return TAMD_RAISE((enum turtle_return)rc, "%s", message);
+        if (tamd_stage_fetch(&st, position, 3 * nb, args.pos) ||
+            tamd_stage_fetch(&st, index, 2 * n * sizeof(int), args.index) ||
+            tamd_stage_fetch(&st, length, nb, args.length) ||
+            tamd_stage_fetch(&st, n_steps, n * sizeof(int), args.n_steps) || tamd_stage_end(&st))
                 return TAMD_RAISE_DEVICE();
         return TURTLE_RETURN_SUCCESS;
 }
