@@ -1625,10 +1625,13 @@ struct PhaseIO {
         const ull * n_dev;   /* phase B: their number, on the device */
         int * parked;        /* phase A: where to list parked rays (or NULL) */
         ull * n_parked;
-        int park_after;      /* phase A: park at this step count (<= 0: never) */
+        int park_after;      /* phase A: park at this step count (<= 0: never); phase B: the
+                              * step count from which a ray steps on its line (see LINED) */
         int accumulate;      /* 1 (phase B): length / n_steps continue from the arrays; 2 (a
                               * later round of a paged geometry): the tentative step too */
         Paging pg;           /* where to list the rays that need a tile paged in (or NULLs) */
+        int drain_lanes;     /* phase A: hand over when the queue is dry and the wave is down
+                              * to this many rays */
 };
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
@@ -1646,6 +1649,13 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
          * line and position must agree on where a sample is */
         RayLine line;
         line.valid = false, line.s = 0.;
+        /* Which arithmetic a sample uses depends on the ray's step count alone:
+         * below ph.park_after the closed form at the accumulated position, as in
+         * phase A; from there on the ray's line.  Phase A can then hand a ray over
+         * at ANY step (it does, when the queue runs dry: see `drain`) without
+         * changing a bit of the result.  LINED: this lane's ray is on its line. */
+        bool lined_ = false;
+#define LINED (MODEL && lined_)
         /* tiles to page in: stacks only, and only where some are not resident (the
          * bookkeeping costs a wave per SIMD in the one-stack kernel) */
         constexpr bool CAN_FAULT = PAGED && (MODE != TAMD_MODE_ONE_MAP);
@@ -1700,6 +1710,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 len = 0., count = 0, state = ST_INIT;
                                 if (ph.accumulate) len = length[ray], count = n_steps[ray];
                                 count0 = count;
+                                lined_ = MODEL && (count >= ph.park_after);
                                 if (CAN_FAULT && (ph.accumulate == 2)) {
                                         /* a ray that waited for a tile: it carries on
                                          * with the step it was about to take (a fresh
@@ -1715,7 +1726,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         pool_next += min((long)__popcll(mask), avail);
                 }
                 if (__ballot(ray >= 0) == 0) break;
-
                 /* ---- creep loop (phase B, sparse waves) ---------------------------
                  * What is left at the end of a launch is a handful of rays
                  * skimming the ground with ~0.5 m steps for thousands of steps.
@@ -1734,7 +1744,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 double qx = 0, qy = 0, qz = 0;
                                 Sample s;
                                 if (ray >= 0) {
-                                        fail = (state != ST_STEP) || (count + 1 >= max_steps);
+                                        fail = (state != ST_STEP) || (count + 1 >= max_steps) || !lined_;
                                         if (!fail) {
                                                 const double sl = line.s + ds;
                                                 qx = __builtin_fma(dx, sl, bx), qy = __builtin_fma(dy, sl, by);
@@ -1790,7 +1800,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                     f_grid_blend(g, c, cell.lo, cell.hi) + ctx.offset;
                                 const double clearance = fabs(alt - elevation);
                                 const int mm = (elevation >= alt) ? 0 : 1;
-                                const bool ok = (ray >= 0) & (state == ST_STEP) &
+                                const bool ok = (ray >= 0) & (state == ST_STEP) & lined_ &
                                     (count + 1 < max_steps) & line.valid & (fabs(sl) <= kLineRange) &
                                     f_line_serves(line, sl, clearance) & interior &
                                     (c.id == cell.id) & (mm == m);
@@ -1808,16 +1818,23 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         }
                 }
 
-                bool park = false;
+                /* `drain`: once the queue is dry a wave of phase A hands its rays over
+                 * as they stand (between two steps) instead of stepping its last few
+                 * to their 512th step with most lanes idle -- measured: the queue of
+                 * C2 is dry after 2.4 ms and the last wave left at 4.5 ms.  Phase B
+                 * packs them again, and has the time: it waits for its longest ray. */
+                const bool drain = !MODEL && (ph.park_after > 0) && exhausted && (ray >= 0) &&
+                    (state == ST_STEP) && (__popcll(__ballot(ray >= 0)) <= ph.drain_lanes);
+                bool park = drain;
                 TileFault fault = { -1, 0, 0 }; /* the tiles to page in, if any */
                 double fx = 0, fy = 0, fz = 0; /* where the ray goes back to, then */
-                if (ray >= 0) {
+                if ((ray >= 0) && !drain) {
                         /* ---- one sample at q = B + d * t ---- */
                         double t = 0.;
                         if (state == ST_STEP) t = ds;
                         if (state == ST_BISECT) t = 0.5 * (ds0 + ds1);
                         double qx = bx, qy = by, qz = bz;
-                        if (MODEL && (state != ST_INIT)) {
+                        if (LINED && (state != ST_INIT)) {
                                 const double sl = line.s + t;
                                 qx = __builtin_fma(dx, sl, bx), qy = __builtin_fma(dy, sl, by);
                                 qz = __builtin_fma(dz, sl, bz);
@@ -1825,7 +1842,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
 
                         Sample s;
-                        if (MODEL) {
+                        if (LINED) {
                                 /* B's parameter: -t on a new line (its origin is q),
                                  * and a STEP sample then moves B to q */
                                 if (f_sample_on_line<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line,
@@ -1844,7 +1861,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 fault = s.fault;
                                 if (state == ST_INIT) home = -1; /* a new ray: nothing to keep */
                                 double back = (state == ST_BISECT) ? ds : 0.;
-                                if (MODEL) {
+                                if (LINED) {
                                         back += (state == ST_STEP) ? t : 0.;
                                         const double sb = line.s - back;
                                         fx = __builtin_fma(dx, sb, bx), fy = __builtin_fma(dy, sb, by);
@@ -1891,7 +1908,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 const bool other = !same;              /* a sample of another medium */
                                 const double ds_next = d_step_length(v, s.alt, s.e0, s.e1, s.m);
                                 /* a STEP sample always moves B to q */
-                                if (!MODEL)
+                                if (!LINED)
                                         bx = stepping ? qx : bx, by = stepping ? qy : by,
                                         bz = stepping ? qz : bz;
                                 len = accept ? len + ds : len;
@@ -1910,12 +1927,22 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 const bool capped = accept & (count >= max_steps);
                                 done = capped;
                                 my_capped += capped ? 1 : 0;
-                                park = accept & !capped & (ph.park_after > 0) & (count >= ph.park_after);
+                                const bool over = accept & !capped & (ph.park_after > 0) &
+                                    (count >= ph.park_after);
+                                park = !MODEL & over; /* phase A: on to phase B */
+                                if (MODEL && over && !lined_) {
+                                        /* phase B: from here on the ray steps on its line,
+                                         * laid by a fresh sample of its position -- what a
+                                         * ray handed over at this very step goes through */
+                                        lined_ = true;
+                                        line.valid = false, line.s = 0.;
+                                        state = ST_INIT;
+                                }
                                 located = (state == ST_BISECT) &
                                     (!(ds1 - ds0 > 1E-08) | (halvings > 1200));
                         }
                         if (located) { /* [ref stepper.c:861-863] */
-                                if (MODEL)
+                                if (LINED)
                                         line.s += ds1;
                                 else
                                         bx = bx + dx * ds1, by = by + dy * ds1, bz = bz + dz * ds1;
@@ -1925,7 +1952,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 done = true;
                         }
                         if (done) {
-                                if (MODEL) {
+                                if (LINED) {
                                         bx = __builtin_fma(dx, line.s, bx), by = __builtin_fma(dy, line.s, by);
                                         bz = __builtin_fma(dz, line.s, bz);
                                 }
@@ -2425,9 +2452,10 @@ static int launch_trace_(struct tamd_view view, long n, bool n_on_device, double
         const long useful = (n + 255) / 256;
         if (!n_on_device && (blocks > useful)) blocks = useful;
         if (n_on_device) {
-                /* the parked rays are a few percent of n, and long: spread them
-                 * thin (down to one wave per SIMD) so that each advances fast */
-                long wide = useful / 8;
+                /* phase B: the rays phase A handed over -- the long ones (a few
+                 * percent of n) and whatever was in flight when its queue ran dry
+                 * (up to one ray per lane): at most a quarter of n in practice */
+                long wide = useful / 2;
                 if (wide < (long)g_cus) wide = (long)g_cus;
                 if (blocks > wide) blocks = wide;
         }
@@ -2473,7 +2501,7 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
 {
         const bool again = (pg.ids != nullptr);
         if (again) flags |= TRACE_CARRY_MEDIUM;
-        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, again ? 2 : 0, pg };
+        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, again ? 2 : 0, pg, 0 };
         if (g_math_strict || !view.fast_ok)
                 return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
@@ -2482,11 +2510,16 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
             (n_steps == nullptr))
                 return launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
-        const PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, again ? 2 : 0, pg };
+        static int drain_lanes = -1;
+        if (drain_lanes < 0) {
+                const char * env = getenv("TURTLE_AMD_DRAIN");
+                drain_lanes = ((env != nullptr) && (*env != 0)) ? atoi(env) : 64;
+        }
+        const PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, again ? 2 : 0, pg, drain_lanes };
         if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
                 n_steps, flags, a, stats, queue))
                 return 1;
-        const PhaseIO b = { parked, queue + 2, nullptr, nullptr, 0, 1, pg };
+        const PhaseIO b = { parked, queue + 2, nullptr, nullptr, park, 1, pg, 0 };
         return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
             n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1);
 }
