@@ -2454,8 +2454,15 @@ static int launch_trace_(struct tamd_view view, long n, bool n_on_device, double
         if (n_on_device) {
                 /* phase B: the rays phase A handed over -- the long ones (a few
                  * percent of n) and whatever was in flight when its queue ran dry
-                 * (up to one ray per lane): at most a quarter of n in practice */
-                long wide = useful / 2;
+                 * (up to one ray per lane): as many blocks as fit, or as there can
+                 * be work for (TURTLE_AMD_TAIL_DIV: fewer, for experiments) */
+                static int div = 0;
+                if (div == 0) {
+                        const char * env = getenv("TURTLE_AMD_TAIL_DIV");
+                        div = ((env != nullptr) && (*env != 0)) ? atoi(env) : 1;
+                        if (div < 1) div = 1;
+                }
+                long wide = useful / div;
                 if (wide < (long)g_cus) wide = (long)g_cus;
                 if (blocks > wide) blocks = wide;
         }
