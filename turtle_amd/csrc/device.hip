@@ -1578,6 +1578,7 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
 /* ---- the hot kernel ---------------------------------------------------- */
 
 constexpr int kChunk = 64; /* rays a wave draws from the global queue at once */
+constexpr int kTailChunk = 8; /* ... in the last phase of a fast trace: few, and long */
 constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many live lanes */
 
 enum { ST_INIT = 0, ST_STEP = 1, ST_BISECT = 2 };
@@ -1625,13 +1626,16 @@ struct PhaseIO {
         const ull * n_dev;   /* phase B: their number, on the device */
         int * parked;        /* phase A: where to list parked rays (or NULL) */
         ull * n_parked;
-        int park_after;      /* phase A: park at this step count (<= 0: never); phase B: the
-                              * step count from which a ray steps on its line (see LINED) */
+        int park_after;      /* hand a ray over to the next phase at this step count (<= 0: never) */
         int accumulate;      /* 1 (phase B): length / n_steps continue from the arrays; 2 (a
                               * later round of a paged geometry): the tentative step too */
         Paging pg;           /* where to list the rays that need a tile paged in (or NULLs) */
         int drain_lanes;     /* phase A: hand over when the queue is dry and the wave is down
                               * to this many rays */
+        int line_after;      /* phases B, C: the step count from which a ray steps on its
+                              * line (see LINED) */
+        int chunk;           /* rays a wave draws from the queue at once */
+        int creep_lanes;     /* the creep loop engages at or below this many live lanes */
 };
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
@@ -1650,7 +1654,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         RayLine line;
         line.valid = false, line.s = 0.;
         /* Which arithmetic a sample uses depends on the ray's step count alone:
-         * below ph.park_after the closed form at the accumulated position, as in
+         * below ph.line_after the closed form at the accumulated position, as in
          * phase A; from there on the ray's line.  Phase A can then hand a ray over
          * at ANY step (it does, when the queue runs dry: see `drain`) without
          * changing a bit of the result.  LINED: this lane's ray is on its line. */
@@ -1687,10 +1691,10 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 }
                                 ull base = 0;
                                 if ((threadIdx.x & 63) == 0)
-                                        base = atomicAdd(queue, (ull)kChunk);
+                                        base = atomicAdd(queue, (ull)ph.chunk);
                                 base = __shfl(base, 0, 64);
                                 pool_next = (long)base;
-                                pool_end = min((long)base + kChunk, n);
+                                pool_end = min((long)base + ph.chunk, n);
                                 if ((long)base >= n) {
                                         exhausted = true;
                                         pool_next = pool_end = 0;
@@ -1710,7 +1714,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 len = 0., count = 0, state = ST_INIT;
                                 if (ph.accumulate) len = length[ray], count = n_steps[ray];
                                 count0 = count;
-                                lined_ = MODEL && (count >= ph.park_after);
+                                lined_ = MODEL && (count >= ph.line_after);
                                 if (CAN_FAULT && (ph.accumulate == 2)) {
                                         /* a ray that waited for a tile: it carries on
                                          * with the step it was about to take (a fresh
@@ -1738,7 +1742,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                  * the same values as the general path, so results do not depend
                  * on whether it engaged. */
                 if (MODEL && (MODE != TAMD_MODE_ONE_MAP) &&
-                    (__popcll(__ballot(ray >= 0)) <= kCreepLanes)) {
+                    (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
                         for (int it = 0; it < 4096; it++) {
                                 bool fail = false;
                                 double qx = 0, qy = 0, qz = 0;
@@ -1776,7 +1780,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                  * the cached cell (no closed form, no fetch inside; a lane that
                  * needs either leaves for one general iteration). */
                 if (MODEL && (MODE == TAMD_MODE_ONE_MAP) &&
-                    (__popcll(__ballot(ray >= 0)) <= kCreepLanes)) {
+                    (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
                         const tamd_grid & g = ctx.grid;
                         const double mx = (double)(g.nx - 1) - 1e-6, my = (double)(g.ny - 1) - 1e-6;
                         for (int it = 0; it < 4096; it++) {
@@ -1927,10 +1931,11 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 const bool capped = accept & (count >= max_steps);
                                 done = capped;
                                 my_capped += capped ? 1 : 0;
-                                const bool over = accept & !capped & (ph.park_after > 0) &
-                                    (count >= ph.park_after);
-                                park = !MODEL & over; /* phase A: on to phase B */
-                                if (MODEL && over && !lined_) {
+                                /* on to the next phase (always at the same step count:
+                                 * the line a ray lays there is part of its arithmetic) */
+                                park = accept & !capped & (ph.park_after > 0) & (count >= ph.park_after);
+                                if (MODEL && accept && !capped && !park && !lined_ &&
+                                    (count >= ph.line_after)) {
                                         /* phase B: from here on the ray steps on its line,
                                          * laid by a fresh sample of its position -- what a
                                          * ray handed over at this very step goes through */
@@ -1977,6 +1982,10 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pmask >> 32),
                                     __builtin_amdgcn_mbcnt_lo((unsigned)pmask, 0));
                                 ph.parked[base + rank] = (int)ray;
+                                if (LINED) {
+                                        bx = __builtin_fma(dx, line.s, bx), by = __builtin_fma(dy, line.s, by);
+                                        bz = __builtin_fma(dz, line.s, bz);
+                                }
                                 pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
                                 index[2 * ray] = m, index[2 * ray + 1] = k;
                                 length[ray] = len;
@@ -2486,21 +2495,53 @@ static int launch_trace(struct tamd_view view, long n, bool n_on_device, double 
             index, length, n_steps, flags, ph, stats, queue);
 }
 
-/* Step count at which phase A parks a ray (fast math only; 0 disables the
- * second phase).  TURTLE_AMD_PARK overrides it for experiments. */
+static int env_int(const char * name, int fallback)
+{
+        const char * env = getenv(name);
+        return ((env != nullptr) && (*env != 0)) ? atoi(env) : fallback;
+}
+
+/* Step counts at which a ray moves on to the next phase of a fast trace (0: no
+ * further phase), and the rays a wave of phase A may still hold when it hands
+ * over after the queue ran dry.  TURTLE_AMD_* override them for experiments. */
 static int park_threshold(void)
 {
         static int value = -1;
-        if (value < 0) {
-                const char * env = getenv("TURTLE_AMD_PARK");
-                value = ((env != nullptr) && (*env != 0)) ? atoi(env) : 512;
-                if (value < 0) value = 0;
-        }
+        if (value < 0) value = max(0, env_int("TURTLE_AMD_PARK", 512));
+        return value;
+}
+static int park_threshold_2(void)
+{
+        static int value = -1;
+        if (value < 0) value = max(0, env_int("TURTLE_AMD_PARK2", 0));
+        return value;
+}
+static int creep_lanes(void)
+{
+        static int value = -1;
+        if (value < 0) value = env_int("TURTLE_AMD_CREEP_LANES", kCreepLanes);
+        return value;
+}
+static int drain_lanes(void)
+{
+        static int value = -1;
+        if (value < 0) value = env_int("TURTLE_AMD_DRAIN", 64);
         return value;
 }
 
 /* One round of a trace: all the rays (pg.ids == NULL), or the ones the last
- * round listed because they needed a tile (they carry on from the arrays). */
+ * round listed because they needed a tile (they carry on from the arrays).
+ *
+ * Fast arithmetic runs in phases, each with fewer and longer rays than the one
+ * before: A steps everything to 512 steps and hands over what is left when its
+ * queue runs dry (C2: 260 k of 1 M rays); B takes those to the end.  A ray
+ * changes phase at fixed step counts, or (below 512 steps) where its arithmetic
+ * does not depend on the phase: see LINED.  A third phase C for the rays beyond
+ * a second threshold (TURTLE_AMD_PARK2; a few to a wave, on an otherwise empty
+ * chip) is wired in but off: measured on C2, every threshold from 544 to 2 048
+ * made the trace slower (8.5-9.5 ms against 7.5 ms) -- what phase B waits for
+ * is not its one longest ray but the medium ones (1 000-2 500 steps) stepping in
+ * waves that are neither full nor down to a handful of rays. */
 template <int MODE>
 static int run_trace(struct tamd_view view, long n, double * pos, const double * dir,
     int max_steps, int * index, double * length, int * n_steps, int flags, int * parked,
@@ -2508,7 +2549,8 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
 {
         const bool again = (pg.ids != nullptr);
         if (again) flags |= TRACE_CARRY_MEDIUM;
-        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, again ? 2 : 0, pg, 0 };
+        const int resume = again ? 2 : 0;
+        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, resume, pg, 0, 0, kChunk, creep_lanes() };
         if (g_math_strict || !view.fast_ok)
                 return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
@@ -2517,22 +2559,27 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
             (n_steps == nullptr))
                 return launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
-        static int drain_lanes = -1;
-        if (drain_lanes < 0) {
-                const char * env = getenv("TURTLE_AMD_DRAIN");
-                drain_lanes = ((env != nullptr) && (*env != 0)) ? atoi(env) : 64;
-        }
-        const PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, again ? 2 : 0, pg, drain_lanes };
+        /* lists: parked[0 .. n) from A to B, parked[n .. 2n) from B to C; counters:
+         * queue[0], [1], [3]: the work queues of A, B, C; queue[2], [4]: the lists */
+        int park2 = park_threshold_2();
+        if ((park2 <= park) || (max_steps <= park2)) park2 = 0;
+        const PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, resume, pg, drain_lanes(), 0,
+                kChunk, creep_lanes() };
         if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
                 n_steps, flags, a, stats, queue))
                 return 1;
-        const PhaseIO b = { parked, queue + 2, nullptr, nullptr, park, 1, pg, 0 };
+        const PhaseIO b = { parked, queue + 2, park2 ? parked + n : nullptr, queue + 4, park2, 1, pg,
+                0, park, kChunk, creep_lanes() };
+        if (launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
+                n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1))
+                return 1;
+        if (park2 == 0) return 0;
+        const PhaseIO c = { parked + n, queue + 4, nullptr, nullptr, 0, 1, pg, 0, park, kTailChunk, creep_lanes() };
         return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
-            n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1);
+            n_steps, flags | TRACE_CARRY_MEDIUM, c, stats, queue + 3);
 }
 
-/* queue[0], queue[1]: work counters of the two phases; queue[2]: parked rays.
- * pg: the round of a paged geometry (paging.c), all NULL otherwise; the
+/* queue: five counters (see run_trace); parked: room for 2 n ray ids.  pg: the round of a paged geometry (paging.c), all NULL otherwise; the
  * counters in `stats` add up over the rounds of a call. */
 extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
@@ -2541,7 +2588,7 @@ extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
 {
         if (tamd_dev_init()) return 1;
         if (pg.ids == nullptr) HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
-        HIP_TRY(hipMemsetAsync(queue, 0, 3 * sizeof(ull), g_stream));
+        HIP_TRY(hipMemsetAsync(queue, 0, 5 * sizeof(ull), g_stream));
         if (n <= 0) return 0;
         const int carry = (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0;
         if (view.mode == TAMD_MODE_ONE_MAP)
