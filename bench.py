@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_CLOCK_HZ = 2.4e9   # MI355X peak engine clock (MI355X_MICROARCH.md)
 TRACE_KERNEL = "k_trace (phase A: all rays up to 512 steps; phase B: the parked long rays)"
 STEP_KERNELS = "k_step + k_bisect per generation (single steps; rays that cross a boundary bisected packed)"
 
@@ -46,8 +47,9 @@ def measured_traffic(workload, rays, math):
         except (OSError, ValueError):
             continue
         if (d.get("workload"), d.get("rays_per_gpu"), d.get("math")) == (workload, rays, math):
-            return d.get("traffic_bytes_per_launch"), os.path.basename(path)
-    return None, None
+            valu = sum(k.get("SQ_INSTS_VALU", 0.0) for k in d.get("kernels", {}).values())
+            return d.get("traffic_bytes_per_launch"), os.path.basename(path), valu
+    return None, None, None
 
 
 def host_cores():
@@ -276,7 +278,11 @@ def main():
             alg_bytes = 8.0 * stats["samples"] + 144.0 * n
             launches = args.scatter_steps
         achieved = alg_bytes * launches / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(args.workload, n, TA.get_math())
+        traffic, traffic_src, valu = measured_traffic(args.workload, n, TA.get_math())
+        # the bound that does apply: wave64 VALU instructions issue at one per 4
+        # cycles per SIMD (counted offline: SQ_INSTS_VALU of the same command)
+        simds = 4 * TA.compute_units()
+        valu_frac = (4.0 * valu / (simds * kernel_ms * 1e-3 * VALU_CLOCK_HZ)) if valu else None
         line = {
             "metric": "ray-steps/sec (whole node) through 3601^2 SRTM tile",
             "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
@@ -297,10 +303,13 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes * launches,
+                         "valu_issue_frac": valu_frac,
                          "note": "achieved = algorithmic bytes / kernel time; traffic = "
                                  "FETCH_SIZE+WRITE_SIZE bytes per launch (PMC, offline). The "
                                  "kernel is fp64-VALU/latency shaped, not bandwidth shaped: "
-                                 "see DESIGN.md"},
+                                 "valu_issue_frac = wave-VALU instructions x 4 cycles / (SIMDs x "
+                                 "kernel time x 2.4 GHz), whole launch (the bulk phase alone: "
+                                 "0.76); see DESIGN.md"},
             "tally": {"hits": [int(v) for v in tally[t_hits].tolist()]},
         }
         if not args.no_cpu and world == 1:
