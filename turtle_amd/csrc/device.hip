@@ -540,9 +540,33 @@ __device__ __noinline__ void d_unproject(
 
 /* ---- one grid --------------------------------------------------------- */
 
+/* Where node (ix, iy) sits in HBM: the grid is stored in blocks of 8 x 8 nodes
+ * (128 bytes = one cache line: internal.h), so that the four nodes of a cell --
+ * and the cells a ray visits next, whichever way it heads -- share a line far
+ * more often than in rows of 7 KB. */
+__device__ __forceinline__ unsigned d_node_index(int nbx, int ix, int iy)
+{
+        return (((unsigned)iy >> 3) * (unsigned)nbx + ((unsigned)ix >> 3)) * 64u +
+            (((unsigned)iy & 7u) << 3) + ((unsigned)ix & 7u);
+}
+
+/* the four raw nodes of cell (ix, iy): lo = z00 | z10 << 16, hi = z01 | z11 << 16.
+ * One index computation; the neighbours are +1 / +8 inside a block, and a jump
+ * to the next block at its last column / row. */
+__device__ __forceinline__ void d_cell_fetch(
+    const uint16_t * nodes, int nbx, int ix, int iy, unsigned & lo, unsigned & hi)
+{
+        global_nodes_t p = GLOBAL_NODES(nodes) + d_node_index(nbx, ix, iy);
+        const unsigned right = (((unsigned)ix & 7u) == 7u) ? 57u : 1u;           /* 64 - 7 */
+        const unsigned up = (((unsigned)iy & 7u) == 7u) ? (unsigned)nbx * 64u - 56u : 8u;
+        const unsigned z00 = p[0], z10 = p[right];
+        const unsigned z01 = p[up], z11 = p[up + right];
+        lo = z00 | (z10 << 16), hi = z01 | (z11 << 16);
+}
+
 __device__ __forceinline__ double d_node(const tamd_grid & g, int ix, int iy)
 {
-        const uint16_t raw = GLOBAL_NODES(g.nodes)[(long)iy * g.nx + ix];
+        const uint16_t raw = GLOBAL_NODES(g.nodes)[d_node_index(g.nbx, ix, iy)];
         const double v = g.is_signed ? (double)(int16_t)raw : (double)raw;
         return g.z0 + v * g.dz; /* [ref map.c:41-44]; exact for z0=0, dz=1 */
 }
@@ -618,10 +642,7 @@ __device__ __forceinline__ bool f_grid_elevation(
         if ((cache != nullptr) && (cache->id == c.id)) {
                 lo = cache->lo, hi = cache->hi;
         } else {
-                global_nodes_t p = GLOBAL_NODES(g.nodes) + c.id;
-                typedef unsigned __attribute__((aligned(2))) u32_a2;
-                lo = *(const __attribute__((address_space(1))) u32_a2 *)p;
-                hi = *(const __attribute__((address_space(1))) u32_a2 *)(p + g.nx);
+                d_cell_fetch(g.nodes, g.nbx, c.ix, c.iy, lo, hi);
                 if (cache != nullptr) cache->id = c.id, cache->lo = lo, cache->hi = hi;
         }
         z = f_grid_blend(g, c, lo, hi);
@@ -871,10 +892,7 @@ __device__ __forceinline__ int f_stack_elevation(const tamd_view & v,
                         if ((cache != nullptr) && (cache->id == id)) {
                                 lo = cache->lo, hi = cache->hi;
                         } else {
-                                global_nodes_t q = GLOBAL_NODES(nodes) + cell;
-                                typedef unsigned __attribute__((aligned(2))) u32_a2;
-                                lo = *(const __attribute__((address_space(1))) u32_a2 *)q;
-                                hi = *(const __attribute__((address_space(1))) u32_a2 *)(q + p.nx);
+                                d_cell_fetch(nodes, p.nbx, ix, iy, lo, hi);
                                 if (cache != nullptr)
                                         cache->id = id, cache->lo = lo, cache->hi = hi;
                         }

@@ -241,13 +241,28 @@ void turtle_map_meta(const struct turtle_map * map, struct turtle_map_info * inf
 
 int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
 {
-        const size_t bytes = (size_t)map->nx * map->ny * sizeof(*map->nodes);
+        /* HBM layout: blocks of TAMD_BLOCK x TAMD_BLOCK nodes (internal.h) */
+        const size_t nbx = ((size_t)map->nx + TAMD_BLOCK - 1) / TAMD_BLOCK;
+        const size_t nby = ((size_t)map->ny + TAMD_BLOCK - 1) / TAMD_BLOCK;
+        const size_t bytes = nbx * nby * TAMD_BLOCK * TAMD_BLOCK * sizeof(*map->nodes);
         if (map->d_nodes == NULL) {
                 if (tamd_dev_malloc(&map->d_nodes, bytes)) return 1;
                 map->d_stale = 1;
         }
         if (map->d_stale) {
-                if (tamd_dev_h2d(map->d_nodes, map->nodes, bytes)) return 1;
+                uint16_t * blocked = calloc(1, bytes);
+                if (blocked == NULL) return 1;
+                int ix, iy;
+                for (iy = 0; iy < map->ny; iy++) {
+                        const uint16_t * row = map->nodes + (size_t)iy * map->nx;
+                        uint16_t * to = blocked + ((size_t)(iy / TAMD_BLOCK) * nbx) * (TAMD_BLOCK * TAMD_BLOCK) +
+                            (size_t)(iy % TAMD_BLOCK) * TAMD_BLOCK;
+                        for (ix = 0; ix < map->nx; ix++)
+                                to[(size_t)(ix / TAMD_BLOCK) * (TAMD_BLOCK * TAMD_BLOCK) + ix % TAMD_BLOCK] = row[ix];
+                }
+                const int failed = tamd_dev_h2d(map->d_nodes, blocked, bytes);
+                free(blocked);
+                if (failed) return 1;
                 map->d_stale = 0;
         }
         if (grid != NULL) {
@@ -260,7 +275,7 @@ int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
                 grid->z0 = map->is_signed ? 0. : map->z0;
                 grid->dz = map->is_signed ? 1. : map->dz;
                 grid->is_signed = map->is_signed;
-                grid->pad_ = 0;
+                grid->nbx = (int)nbx;
                 tamd_projection_desc(&map->projection, &grid->proj);
         }
         return 0;
