@@ -869,8 +869,11 @@ __device__ __forceinline__ int f_stack_elevation(const tamd_view & v,
 {
         if (st.regular) {
                 const tamd_grid & p = st.proto;
-                const double fx = (longitude - st.lon0) / st.dlon;
-                const double fy = (latitude - st.lat0) / st.dlat;
+                /* 1/dlon, 1/dlat: a last-ulp difference from the quotient can only
+                 * pick the neighbouring tile for a point ON a seam, which is then
+                 * not `interior` below and goes the exact way */
+                const double fx = (longitude - st.lon0) * st.inv_dlon;
+                const double fy = (latitude - st.lat0) * st.inv_dlat;
                 const bool in_dir =
                     (fx > 0.) && (fx < (double)st.nlon) && (fy > 0.) && (fy < (double)st.nlat);
                 const int tx = in_dir ? (int)fx : 0, ty = in_dir ? (int)fy : 0;

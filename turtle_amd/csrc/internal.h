@@ -66,6 +66,7 @@ struct tamd_grid {
  * replaces the reference's MRU list scan [ref stack.c:300-335]. */
 struct tamd_stack {
         double lat0, lon0, dlat, dlon;
+        double inv_dlat, inv_dlon; /* the fast-math lookup multiplies (seams: exact) */
         int nlat, nlon;
         int tile_first; /* offset into the tiles[] table: grid index or -1 */
         /* `regular`: every tile present has the same shape and encoding (nx,

@@ -358,6 +358,7 @@ static int stack_view(struct turtle_stack * s, struct tamd_view * view, char * m
         }
         st->lat0 = s->latitude_0, st->lon0 = s->longitude_0;
         st->dlat = s->latitude_delta, st->dlon = s->longitude_delta;
+        st->inv_dlat = 1. / st->dlat, st->inv_dlon = 1. / st->dlon;
         st->nlat = s->latitude_n, st->nlon = s->longitude_n;
         st->tile_first = 0;
         meta->kind = TAMD_STACK;

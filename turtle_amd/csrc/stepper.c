@@ -276,6 +276,7 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
                         struct tamd_stack * t = &stacks[stack_count];
                         t->lat0 = st->latitude_0, t->lon0 = st->longitude_0;
                         t->dlat = st->latitude_delta, t->dlon = st->longitude_delta;
+                        t->inv_dlat = 1. / t->dlat, t->inv_dlon = 1. / t->dlon;
                         t->nlat = st->latitude_n, t->nlon = st->longitude_n;
                         t->tile_first = tile_count;
                         const int slots = st->latitude_n * st->longitude_n;
