@@ -580,6 +580,10 @@ __device__ __forceinline__ double d_node(const tamd_grid & g, int ix, int iy)
 struct CellCache {
         unsigned id;     /* iy * nx + ix, or ~0u when empty */
         unsigned lo, hi; /* (z00 | z10 << 16), (z01 | z11 << 16), raw codes */
+        /* regular stacks: the tile the last lookup fell in, and its nodes (saves the
+         * dependent pointer load of every sample that stays in the tile) */
+        int slot;
+        const uint16_t * tile;
 };
 
 /* [ref map.c:229-277], fast-math form.  Differences from the strict form, none
@@ -884,8 +888,15 @@ __device__ __forceinline__ int f_stack_elevation(const tamd_view & v,
                 const bool interior =
                     in_dir && (hx > 1e-6) && (hx < mx) && (hy > 1e-6) && (hy < my);
                 const int slot = ty * st.nlon + tx;
-                const uint16_t * nodes =
-                    interior ? v.slot_nodes[st.nodes_first + slot] : nullptr;
+                const uint16_t * nodes = nullptr;
+                if (interior) {
+                        if ((cache != nullptr) && (cache->slot == slot))
+                                nodes = cache->tile;
+                        else {
+                                nodes = v.slot_nodes[st.nodes_first + slot];
+                                if (cache != nullptr) cache->slot = slot, cache->tile = nodes;
+                        }
+                }
                 if (nodes != nullptr) {
                         const int ix = (int)hx, iy = (int)hy;
                         const double fxc = hx - (double)ix, fyc = hy - (double)iy;
@@ -1535,7 +1546,7 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
                 double px = pos[3 * r], py = pos[3 * r + 1], pz = pos[3 * r + 2];
                 const double dx = dir[3 * r], dy = dir[3 * r + 1], dz = dir[3 * r + 2];
                 const int medium0 = index[2 * r];
-                CellCache cell = { ~0u, 0u, 0u };
+                CellCache cell = { ~0u, 0u, 0u, -1, nullptr };
                 CellCache * cache = (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr;
                 Sample s;
                 /* fast math: the bracket is a segment of the ray behind q, so the
@@ -1688,7 +1699,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         bool exhausted = false;            /* wave-uniform */
         OneCtx ctx;
         d_load_ctx<MODE>(v, ctx);
-        CellCache cell = { ~0u, 0u, 0u };
+        CellCache cell = { ~0u, 0u, 0u, -1, nullptr };
 
         long ray = -1;
         bool dead = false;
