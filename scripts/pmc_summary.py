@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc CSVs: per kernel, mean counter value per dispatch."""
+"""Summarise rocprofv3 --pmc CSVs: per kernel, mean counter value per dispatch.
+PMC_TAIL=<fraction>: only the last such fraction of each kernel's dispatches (a
+workload that changes as it runs: the scattering walk's later generations)."""
 import csv
 import glob
+import os
 import sys
 from collections import defaultdict
 
@@ -14,9 +17,11 @@ for path in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
         if want not in name:
             continue
         short = name[name.find(want):].split("(")[0] + " grid=" + row["Grid_Size"]
-        acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        acc[short][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
 for kern, ctr in acc.items():
     print(f"== {kern}")
     for c in sorted(ctr):
-        v = ctr[c]
+        v = [x for _, x in sorted(ctr[c])]
+        tail = float(os.environ.get("PMC_TAIL", "1"))
+        v = v[int(len(v) * (1 - tail)):]
         print(f"  {c:28s} mean/dispatch {sum(v) / len(v):.6g}   (n={len(v)})")

@@ -223,6 +223,52 @@ def test_stack_directory(golden, tmp_path, math):
     one.destroy()
 
 
+def test_stack_rim_and_seams(tmp_path, math):
+    """Samples hugging the mosaic's rim and the seams between its tiles, from both
+    sides, 1e-12 to 1e-4 degree away (1e-7 m to 10 m): the stepper's answer --
+    inside or not, which elevation -- is the reference's.  This is where a ray
+    leaving the mosaic is bisected, and where the fast lookup hands over to the
+    exact one (device.hip: kSeamGuard, kRimGuard)."""
+    tiles = [(45, 3), (45, 4), (46, 3), (46, 4)]
+    n = 1201  # the .hgt reader knows two sizes [ref io/hgt.c:98-104]
+    stack = B.mosaic(tmp_path, tiles, n)
+    geo = T.mosaic_oracle(tiles, n, 45, 3, 2, 2)
+    st = TA.Stepper()
+    st.add_stack(stack, 0.0)
+    eps = np.array([1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4])
+    off = np.concatenate([-eps[::-1], eps])
+    edges = np.array([45.0, 46.0, 47.0])
+    along = np.linspace(45.03, 46.97, 23)
+    lat, lon = [], []
+    for e in edges:
+        for o in off:
+            lat += [np.full(along.size, e + o), along]          # horizontal line at lat = e + o
+            lon += [along - 42.0, np.full(along.size, e - 42.0 + o)]  # vertical at lon = e - 42 + o
+    lat, lon = np.concatenate(lat), np.concatenate(lon)
+    # the corners too: both coordinates on an edge at once
+    cl, co = np.meshgrid(edges, edges - 42.0)
+    for o1 in off[::4]:
+        for o2 in off[::4]:
+            lat, lon = np.concatenate([lat, (cl + o1).ravel()]), np.concatenate([lon, (co + o2).ravel()])
+    pos = O.ecef_from_geodetic(lat, lon, np.full(lat.size, 2500.0))
+    mine = st.step(pos.copy(), None)
+    ref = geo.step(pos)
+    assert np.array_equal(mine["index"], ref["index"])
+    inside = ref["index"][:, 0] >= 0
+    assert inside.sum() > 0.4 * lat.size and (~inside).sum() > 0.2 * lat.size
+    assert np.abs(mine["elevation"][inside] - ref["elevation"][inside]).max() < 1e-9
+    # and one step from there: a ray that has left keeps answering "outside"
+    d = TA.isotropic(lat.size, 7, 0, device=False)
+    mine2 = st.step(mine["position"], d, resume=mine)
+    ref2 = geo.step(ref["position"], d)
+    same = mine2["index"][:, 0] == ref2["index"][:, 0]
+    assert (~same).sum() <= 2, np.flatnonzero(~same)[:10]
+    ok = same & (ref2["index"][:, 0] >= 0)
+    assert np.abs(mine2["step"][ok] - ref2["step"][ok]).max() < 1e-6 * ref2["step"][ok].max()
+    st.destroy()
+    stack.destroy()
+
+
 @pytest.mark.parametrize("name", ["nogeoid", "geoid"])
 def test_layers_offsets_flat_geoid(golden, name, math):
     g = golden("layers")

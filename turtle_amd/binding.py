@@ -33,7 +33,8 @@ class TurtleError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(HERE, "libturtle_amd.so")
+    # TURTLE_AMD_LIBRARY: another build of the same library (kernel experiments)
+    return os.environ.get("TURTLE_AMD_LIBRARY") or os.path.join(HERE, "libturtle_amd.so")
 
 
 def build(force: bool = False) -> str:

@@ -551,17 +551,27 @@ __device__ __forceinline__ unsigned d_node_index(int nbx, int ix, int iy)
 }
 
 /* the four raw nodes of cell (ix, iy): lo = z00 | z10 << 16, hi = z01 | z11 << 16.
- * One index computation; the neighbours are +1 / +8 inside a block, and a jump
- * to the next block at its last column / row. */
+ * One index computation; the upper row is +8 inside a block, or a jump to the
+ * next block row.  The two nodes of a row are neighbours in memory except in a
+ * block's last column: one 32-bit load (2-byte aligned) fetches both, and only
+ * the lanes in a last column (1 in 8) go back for the node of the next block.
+ * Per wave that is ~144 line look-ups in the vector L1 instead of 256 -- the
+ * gathers are most of what a batch of single steps asks of it.  (The pair load
+ * never overruns the array: a cell's left-hand nodes have ix <= nx - 2, which
+ * is never the last node of the last block.) */
+typedef unsigned __attribute__((aligned(2))) u32_a2;
+typedef const __attribute__((address_space(1))) u32_a2 * global_pair_t;
+
 __device__ __forceinline__ void d_cell_fetch(
     const uint16_t * nodes, int nbx, int ix, int iy, unsigned & lo, unsigned & hi)
 {
         global_nodes_t p = GLOBAL_NODES(nodes) + d_node_index(nbx, ix, iy);
-        const unsigned right = (((unsigned)ix & 7u) == 7u) ? 57u : 1u;           /* 64 - 7 */
         const unsigned up = (((unsigned)iy & 7u) == 7u) ? (unsigned)nbx * 64u - 56u : 8u;
-        const unsigned z00 = p[0], z10 = p[right];
-        const unsigned z01 = p[up], z11 = p[up + right];
-        lo = z00 | (z10 << 16), hi = z01 | (z11 << 16);
+        lo = *(global_pair_t)p, hi = *(global_pair_t)(p + up);
+        if (((unsigned)ix & 7u) == 7u) { /* 64 - 7: the next block's first column */
+                const unsigned z10 = p[57], z11 = p[up + 57];
+                lo = (lo & 0xffffu) | (z10 << 16), hi = (hi & 0xffffu) | (z11 << 16);
+        }
 }
 
 __device__ __forceinline__ double d_node(const tamd_grid & g, int ix, int iy)
@@ -790,6 +800,15 @@ __device__ __forceinline__ bool d_tile_holds(
 struct TileFault {
         int centre, mask, stride;
 };
+constexpr double kRimGuard = 1e-9; /* of a directory cell: ~1e4 x the rounding of fx, fy */
+/* Of a tile cell: how close to a seam the fast lookup trusts hx = (x - x0) * (1/dx)
+ * to land on the same side as the reference's quotient.  The two differ by
+ * < 4 ulp of hx (2e-11 cell for the largest grid, 65 535 nodes a side); 1e-9
+ * leaves a factor 50, and is narrow enough (3e-8 m of a 30 m cell) that the
+ * bisection of an exit through the mosaic's rim -- which converges ON the seam,
+ * to 1e-8 m -- takes the exact way, with its dependent loads, for its last
+ * couple of samples only and not for a dozen. */
+constexpr double kSeamGuard = 1e-9;
 constexpr int kTileFault = TAMD_TILE_PAGED; /* d_stack_tile's return value then */
 
 /* The tile of a stack that answers for a point, -1 for none, or kTileFault
@@ -799,9 +818,17 @@ __device__ __forceinline__ int d_stack_tile(const tamd_view & v, const tamd_stac
 {
         const double fx = (longitude - st.lon0) / st.dlon;
         const double fy = (latitude - st.lat0) / st.dlat;
-        /* no tile box reaches further than one cell from the directory */
-        if (!((fx > -1.5) && (fx < st.nlon + 1.5) && (fy > -1.5) &&
-                (fy < st.nlat + 1.5)))
+        /* No tile box reaches further than one cell from the directory -- and in
+         * a regular stack (tiles exactly on the lattice, each spanning its cell up
+         * to rounding) none reaches beyond its rim: out there the directory
+         * formula [ref stack.c:413-424] finds no tile either.  This early answer
+         * is what a ray that has left the mosaic gets at every later step of a
+         * batch, and half the samples of the bisection of its exit: without it
+         * each of them costs its whole wave the neighbourhood scan below (four
+         * dependent loads, a dozen divisions). */
+        const double reach = st.regular ? kRimGuard : 1.5;
+        if (!((fx > -reach) && (fx < st.nlon + reach) && (fy > -reach) &&
+                (fy < st.nlat + reach)))
                 return -1;
         const int cx = min(max((int)fx, 0), st.nlon - 1);
         const int cy = min(max((int)fy, 0), st.nlat - 1);
@@ -864,12 +891,20 @@ __device__ __forceinline__ int d_stack_elevation(const tamd_view & v,
 
 /* Fast-math lookup in a `regular` stack (see struct tamd_stack): interior
  * points take the tile by the directory formula and read its nodes through one
- * pointer; anything within 1e-6 cell of a tile seam or of the directory's rim,
+ * pointer; anything within kSeamGuard of a cell of a tile seam or of the directory's rim,
  * and any irregular stack, goes through the general routine above, which
  * decides seams and edges exactly as the reference does. */
+/* `slots`: the stack's node pointers, one per directory slot, copied to LDS by
+ * the kernel (see d_load_ctx) when TABLE.  The per-lane copy of the last tile's
+ * pointer is then not needed (8 registers fewer in the trace kernel), and a
+ * sample in a new tile waits for HBM once (the nodes), not twice in a row. */
+typedef const uint16_t * node_ptr_t;
+typedef const __attribute__((address_space(3))) node_ptr_t * lds_slots_t;
+
+template <bool TABLE = false> /* TABLE: `slots` is there whenever the stack is regular */
 __device__ __forceinline__ int f_stack_elevation(const tamd_view & v,
     const tamd_stack & st, double latitude, double longitude, double & z,
-    CellCache * cache, TileFault & f)
+    CellCache * cache, TileFault & f, lds_slots_t slots = nullptr)
 {
         if (st.regular) {
                 const tamd_grid & p = st.proto;
@@ -884,12 +919,14 @@ __device__ __forceinline__ int f_stack_elevation(const tamd_view & v,
                 const double x0 = st.lon0 + tx * st.dlon, y0 = st.lat0 + ty * st.dlat;
                 const double hx = (longitude - x0) * p.inv_dx;
                 const double hy = (latitude - y0) * p.inv_dy;
-                const double mx = (double)(p.nx - 1) - 1e-6, my = (double)(p.ny - 1) - 1e-6;
+                const double mx = (double)(p.nx - 1) - kSeamGuard, my = (double)(p.ny - 1) - kSeamGuard;
                 const bool interior =
-                    in_dir && (hx > 1e-6) && (hx < mx) && (hy > 1e-6) && (hy < my);
+                    in_dir && (hx > kSeamGuard) && (hx < mx) && (hy > kSeamGuard) && (hy < my);
                 const int slot = ty * st.nlon + tx;
                 const uint16_t * nodes = nullptr;
-                if (interior) {
+                if (TABLE) {
+                        if (interior) nodes = slots[slot];
+                } else if (interior) {
                         if ((cache != nullptr) && (cache->slot == slot))
                                 nodes = cache->tile;
                         else {
@@ -971,16 +1008,30 @@ struct OneCtx {
         tamd_grid grid;
         tamd_stack stack;
         double offset;
+        lds_slots_t slots; /* one-stack mode, fast math, regular stack: see f_stack_elevation */
 };
 
-template <int MODE>
+/* Called by every thread of the block, at the top of the kernel (it holds a
+ * barrier when it fills the LDS table: blocks are 256 threads, and a regular
+ * stack has at most 255 slots). */
+template <int MODE, bool FAST = false>
 __device__ __forceinline__ void d_load_ctx(const tamd_view & v, OneCtx & c)
 {
+        c.slots = nullptr;
         if (MODE == TAMD_MODE_GENERIC) return;
         const tamd_meta mt = v.metas[0];
         c.offset = mt.offset;
         if (MODE == TAMD_MODE_ONE_MAP) c.grid = v.grids[mt.src];
         if (MODE == TAMD_MODE_ONE_STACK) c.stack = v.stacks[mt.src];
+        if ((MODE == TAMD_MODE_ONE_STACK) && FAST) {
+                __shared__ node_ptr_t table[256];
+                if (c.stack.regular) {
+                        if ((int)threadIdx.x < c.stack.nlat * c.stack.nlon)
+                                table[threadIdx.x] = v.slot_nodes[c.stack.nodes_first + threadIdx.x];
+                        __syncthreads();
+                        c.slots = (lds_slots_t)table;
+                }
+        }
 }
 
 /* The layers at geodetic coordinates already in s.lat, s.lon, s.alt */
@@ -1001,7 +1052,7 @@ __device__ __forceinline__ void d_classify(
                             d_grid_elevation<false>(ctx.grid, s.lon, s.lat, elevation);
                 else
                         inside = FAST ?
-                            f_stack_elevation(v, ctx.stack, s.lat, s.lon, elevation, cache, s.fault) :
+                            f_stack_elevation<true>(v, ctx.stack, s.lat, s.lon, elevation, cache, s.fault, ctx.slots) :
                             d_stack_elevation<false>(v, ctx.stack, s.lat, s.lon, elevation, s.fault);
                 if ((MODE == TAMD_MODE_ONE_STACK) && (inside >= 0)) s.slot = s.fault.centre;
                 if ((MODE != TAMD_MODE_ONE_STACK) || (inside >= 0)) s.fault.centre = -1;
@@ -1402,14 +1453,14 @@ struct CrossList {
  * Monte-Carlo over a 2.6 GB mosaic is bound by their latency).
  * stats (or NULL): rays, steps, samples, steps that did not cross. */
 template <int MODE, bool FAST>
-__global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
+__device__ __forceinline__ void step_items(const tamd_view & v, long n,
     double * __restrict__ pos, const double * __restrict__ dir,
     double * __restrict__ lat, double * __restrict__ lon, double * __restrict__ alt,
     double * __restrict__ elev, double * __restrict__ step, int * __restrict__ index,
     int flags, CrossList cross, Paging pg, ull * __restrict__ stats)
 {
         OneCtx ctx;
-        d_load_ctx<MODE>(v, ctx);
+        d_load_ctx<MODE, FAST>(v, ctx);
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_plain = 0;
         PAGED_ITEMS(pg, n, i0, r) /* whole waves go round: see the listings */
         {
@@ -1422,8 +1473,10 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
                 Sample s;
                 if ((flags & TURTLE_AMD_STEP_RESUME) && (dir != nullptr) && (index[2 * r] >= 0)) {
                         /* the caller hands back the sample of this position
-                         * [ref stepper.c:708-710, :745-748] */
-                        s.lat = lat ? lat[r] : 0., s.lon = lon ? lon[r] : 0.;
+                         * [ref stepper.c:708-710, :745-748]; its latitude and
+                         * longitude are not read: whatever becomes of the step,
+                         * the ones published are the new sample's */
+                        s.lat = 0., s.lon = 0.;
                         s.alt = alt[r];
                         s.e0 = elev[2 * r], s.e1 = elev[2 * r + 1];
                         s.m = index[2 * r], s.k = index[2 * r + 1];
@@ -1520,6 +1573,31 @@ __global__ void __launch_bounds__(256) k_step(tamd_view v, long n,
         if (stats != nullptr) block_tally(stats, my_rays, my_steps, my_samples, my_plain);
 }
 
+/* The kernel proper, once per arithmetic.  A batch of single steps is bound by
+ * the latency of its dependent loads (ray state -> nodes), so waves in flight
+ * count: the fast-math body of the specialised modes fits 128 registers (4 waves
+ * per SIMD instead of 3: -7 %, measured on C5) when told to; the strict one would
+ * spill 230 bytes a lane for it (+23 %), and so would the fast body of the
+ * generic mode: they are left alone. */
+#define STEP_ARGS                                                                              \
+        tamd_view v, long n, double * __restrict__ pos, const double * __restrict__ dir,       \
+            double * __restrict__ lat, double * __restrict__ lon, double * __restrict__ alt,   \
+            double * __restrict__ elev, double * __restrict__ step, int * __restrict__ index,  \
+            int flags, CrossList cross, Paging pg, ull * __restrict__ stats
+#define STEP_PASS v, n, pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats
+template <int MODE, bool FAST>
+__global__ void __launch_bounds__(256) k_step(STEP_ARGS)
+{
+        step_items<MODE, FAST>(STEP_PASS);
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_step_fast(STEP_ARGS)
+{
+        step_items<MODE, true>(STEP_PASS);
+}
+#undef STEP_ARGS
+#undef STEP_PASS
+
 /* The second pass of a batch of single steps: the bisection of the listed rays
  * [ref stepper.c:836-864], every lane busy.  The ray's position is the tentative
  * point q, its index the medium it left; the first sample (at q again: the
@@ -1532,7 +1610,7 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
     int * __restrict__ index, CrossList cross, Paging pg, ull * __restrict__ stats)
 {
         OneCtx ctx;
-        d_load_ctx<MODE>(v, ctx);
+        d_load_ctx<MODE, FAST>(v, ctx);
         const long n = (long)*cross.count;
         ull my_rays = 0, my_samples = 0;
         for (long i0 = blockIdx.x * (long)blockDim.x; i0 < n; i0 += (long)gridDim.x * blockDim.x) {
@@ -1698,7 +1776,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         long pool_next = 0, pool_end = 0; /* wave-uniform */
         bool exhausted = false;            /* wave-uniform */
         OneCtx ctx;
-        d_load_ctx<MODE>(v, ctx);
+        d_load_ctx<MODE, FAST>(v, ctx);
         CellCache cell = { ~0u, 0u, 0u, -1, nullptr };
 
         long ray = -1;
@@ -2305,6 +2383,7 @@ extern "C" int tamd_scratch_get(void ** ptr, size_t bytes)
 static int grid_for(long n, int block)
 {
         long blocks = (n + block - 1) / block;
+        /* (4, 16 or 64 blocks per CU: the same or worse, measured on the step kernel) */
         const long cap = (long)(g_cus > 0 ? g_cus : 256) * 8;
         if (blocks > cap) blocks = cap;
         if (blocks < 1) blocks = 1;
@@ -2424,8 +2503,11 @@ static int run_step(struct tamd_view view, long n, double * pos, const double * 
                 if (strict)                                                                    \
                         hipLaunchKernelGGL((k_step<MODE, false>), grid, block, 0, g_stream, view, n,   \
                             pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats);      \
-                else                                                                           \
+                else if (MODE == TAMD_MODE_GENERIC)                                            \
                         hipLaunchKernelGGL((k_step<MODE, true>), grid, block, 0, g_stream, view, n,    \
+                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats);      \
+                else                                                                           \
+                        hipLaunchKernelGGL((k_step_fast<MODE>), grid, block, 0, g_stream, view, n,     \
                             pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats);      \
                 LAUNCH_CHECK("k_step");                                                        \
                 if (cross.ray == nullptr) break;                                               \

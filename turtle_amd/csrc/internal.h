@@ -71,7 +71,8 @@ struct tamd_stack {
         int tile_first; /* offset into the tiles[] table: grid index or -1 */
         /* `regular`: every tile present has the same shape and encoding (nx,
          * ny, dx, dy, z0, dz, sign) and sits exactly on the lattice (x0 ==
-         * lon0 + ix*dlon, y0 == lat0 + iy*dlat), as SRTM/ASTER tiles do.  The
+         * lon0 + ix*dlon, y0 == lat0 + iy*dlat) whose cell it spans ((nx-1) dx
+         * == dlon up to rounding), as SRTM/ASTER tiles do.  The
          * fast-math kernels then need one pointer per tile (slot_nodes[
          * nodes_first + slot], NULL for a missing tile) instead of a whole
          * per-lane grid descriptor; `proto` holds the shared shape. */

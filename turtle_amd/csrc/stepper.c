@@ -11,6 +11,7 @@
 #include "host.h"
 
 #include <float.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -345,7 +346,10 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
                             (q->z0 != proto->z0) || (q->dz != proto->dz) ||
                             (q->is_signed != proto->is_signed) ||
                             (q->x0 != t->lon0 + (j % t->nlon) * t->dlon) ||
-                            (q->y0 != t->lat0 + (j / t->nlon) * t->dlat))
+                            (q->y0 != t->lat0 + (j / t->nlon) * t->dlat) ||
+                            /* ... and spans its lattice cell, no more */
+                            (fabs((q->nx - 1) * q->dx - t->dlon) > 1E-10 * fabs(t->dlon)) ||
+                            (fabs((q->ny - 1) * q->dy - t->dlat) > 1E-10 * fabs(t->dlat)))
                                 regular = 0;
                 }
                 t->regular = regular && (proto != NULL);
