@@ -128,6 +128,13 @@ TURTLE_API enum turtle_return turtle_map_create(struct turtle_map ** map,
 TURTLE_API void turtle_map_destroy(struct turtle_map ** map);
 TURTLE_API enum turtle_return turtle_map_load(
     struct turtle_map ** map, const char * path);
+/* [ref include/turtle.h:401-424; impl map.c:165-180] Writes the map as .png
+ * (the reference's map format, projection included) or as .tif (GeoTIFF-16:
+ * maps with z scale [-32767, 32768] and no projection), without libpng /
+ * libtiff; .hgt / .grd / .asc return TURTLE_RETURN_BAD_FORMAT, anything else
+ * TURTLE_RETURN_BAD_EXTENSION, as in the reference. */
+TURTLE_API enum turtle_return turtle_map_dump(
+    const struct turtle_map * map, const char * path);
 TURTLE_API enum turtle_return turtle_map_fill(
     struct turtle_map * map, int ix, int iy, double elevation);
 TURTLE_API enum turtle_return turtle_map_node(const struct turtle_map * map,

@@ -366,3 +366,103 @@ def test_text_grid_ingest():
         node = np.array([[m.node(a, b)[2] for a in range(meta["nx"])] for b in range(meta["ny"])])
         assert np.array_equal(node, g[tag + "_node"])
         m.destroy()
+
+
+def _png_decode(path):
+    """A PNG reader of the test's own (zlib + the five scan-line filters):
+    width, height, the tEXt payloads, the 16-bit samples (rows as stored)."""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    at, texts, idat, head = 8, [], b"", None
+    while at < len(raw):
+        n, kind = struct.unpack(">I4s", raw[at:at + 8])
+        body = raw[at + 8:at + 8 + n]
+        assert struct.unpack(">I", raw[at + 8 + n:at + 12 + n])[0] == zlib.crc32(kind + body)
+        if kind == b"IHDR":
+            head = struct.unpack(">IIBBBBB", body)
+        elif kind == b"tEXt":
+            texts.append(body)
+        elif kind == b"IDAT":
+            idat += body
+        at += 12 + n
+    w, h, depth, colour, _, _, interlace = head
+    assert (depth, colour, interlace) == (16, 0, 0)
+    data = bytearray(zlib.decompress(idat))
+    stride, bpp = 2 * w, 2
+    rows, prev = [], bytearray(stride)
+    for i in range(h):
+        f = data[i * (stride + 1)]
+        cur = bytearray(data[i * (stride + 1) + 1:(i + 1) * (stride + 1)])
+        for k in range(stride):
+            a = cur[k - bpp] if k >= bpp else 0
+            b = prev[k]
+            c = prev[k - bpp] if k >= bpp else 0
+            if f == 1:
+                cur[k] = (cur[k] + a) & 255
+            elif f == 2:
+                cur[k] = (cur[k] + b) & 255
+            elif f == 3:
+                cur[k] = (cur[k] + (a + b) // 2) & 255
+            elif f == 4:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                cur[k] = (cur[k] + (a if (pa <= pb and pa <= pc) else (b if pb <= pc else c))) & 255
+        rows.append(np.frombuffer(bytes(cur), dtype=">u2").astype(np.uint16))
+        prev = cur
+    return w, h, texts, np.array(rows)
+
+
+def test_map_dump(tmp_path):
+    """turtle_map_dump [ref map.c:165-180].  The PNG written from a map that was
+    loaded from a file WRITTEN BY THE REFERENCE (tests/golden/map_utm.png) holds
+    the same samples and, byte for byte, the same "Comment" header as that file
+    [ref png16.c:456-545]; both formats read back as the map that was dumped;
+    the reference's refusals [ref geotiff16.c:266-278, io.c:101-103]."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    theirs = os.path.join(here, "golden", "map_utm.png")
+    m = TA.Map.load(theirs)
+    ours = os.path.join(tmp_path, "again.png")
+    m.dump(ours)
+    w0, h0, t0, s0 = _png_decode(theirs)
+    w1, h1, t1, s1 = _png_decode(ours)
+    assert (w0, h0) == (w1, h1) and np.array_equal(s0, s1)
+    assert t0 == t1 and t1[0].startswith(b"Comment\x00{\"topography\" : {\"x0\" : 0x")
+    back = TA.Map.load(ours)
+    assert back.meta() == m.meta()
+    for ix, iy in ((0, 0), (3, 7), (m.meta()["nx"] - 1, m.meta()["ny"] - 1)):
+        assert back.node(ix, iy) == m.node(ix, iy)
+    back.destroy()
+    with pytest.raises(TA.TurtleError) as e:
+        m.dump(os.path.join(tmp_path, "projected.tif"))   # z scale and projection
+    assert e.value.name == "BAD_FORMAT" and "unsupported z scale" in str(e.value)
+    m.destroy()
+
+    # an int16-scaled geodetic map [ref tests/test-turtle.c:1093-1135], asymmetric on
+    # purpose: a writer that flipped the rows would be caught
+    nx, ny = 31, 17
+    t = TA.Map.create(None, (3.0, 4.0), (45.0, 46.0), (-32767.0, 32768.0), shape=(ny, nx))
+    for iy in range(ny):
+        for ix in range(nx):
+            t.fill(ix, iy, float(7 * iy - 3 * ix))
+    for ext in ("tif", "png"):
+        p = os.path.join(tmp_path, "int16." + ext)
+        t.dump(p)
+        back = TA.Map.load(p)
+        mb, mt = back.meta(), t.meta()
+        assert (mb["nx"], mb["ny"], mb["z"]) == (nx, ny, mt["z"])
+        assert np.allclose(mb["x"], mt["x"], atol=1e-12) and np.allclose(mb["y"], mt["y"], atol=1e-12)
+        for iy in range(ny):
+            for ix in range(0, nx, 5):
+                assert back.node(ix, iy)[2] == 7 * iy - 3 * ix
+        back.destroy()
+    for name, code in (("x.hgt", "BAD_FORMAT"), ("x.grd", "BAD_FORMAT"), ("x.asc", "BAD_FORMAT"),
+                       ("x.jpg", "BAD_EXTENSION"), ("noextension", "BAD_EXTENSION")):
+        with pytest.raises(TA.TurtleError) as e:
+            t.dump(os.path.join(tmp_path, name))
+        assert e.value.name == code
+    with pytest.raises(TA.TurtleError) as e:
+        t.dump(os.path.join(tmp_path, "no", "such", "dir.png"))
+    assert e.value.name == "PATH_ERROR" and "turtle_map_dump" in str(e.value)
+    t.destroy()

@@ -317,6 +317,9 @@ class Map:
         _check(lib().turtle_map_load(C.byref(h), os.fsencode(path)))
         return cls(h)
 
+    def dump(self, path):
+        _check(lib().turtle_map_dump(self.h, os.fsencode(path)))
+
     def fill(self, ix, iy, z):
         _check(lib().turtle_map_fill(self.h, ix, iy, C.c_double(z)))
 

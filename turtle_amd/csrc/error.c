@@ -73,6 +73,7 @@ const char * turtle_error_function(turtle_function_t * caller)
         NAME(turtle_map_gradient_n);
         NAME(turtle_stack_gradient);
         NAME(turtle_stack_gradient_n);
+        NAME(turtle_map_dump);
         NAME(turtle_map_load);
         NAME(turtle_map_meta);
         NAME(turtle_map_node);
