@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--scatter-steps", type=int, default=256, help="c5: steps per ray")
     ap.add_argument("--sort", type=int, default=0,
                     help="experiment: order the rays by origin in an NxN grid of bins")
+    ap.add_argument("--sort-steps", type=int, default=0,
+                    help="experiment: order the rays by their step count (1: longest first, "
+                         "-1: shortest first), known from a trace made beforehand")
     ap.add_argument("--cpu-rays", type=int, default=1_000_000,
                     help="rays of the CPU-baseline sample (default: the whole C2 batch)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -204,6 +207,11 @@ def main():
     t_hits, t_hist, t_steps, t_size = sharding.tally_layout(n_media, n_bins)
     tally = torch.zeros(t_size, dtype=torch.int64, device=dev)
 
+    if args.sort_steps and args.workload != "c5":
+        pos.copy_(pos0)
+        stepper.trace_into(pos, direction, index, length, nsteps, args.max_steps)
+        order = torch.argsort(nsteps, descending=args.sort_steps > 0, stable=True)
+        pos0, direction = pos0[order].contiguous(), direction[order].contiguous()
     scatter = args.workload == "c5"
     first_ray = rank * n
     direction_k = torch.empty_like(pos0) if scatter else None
