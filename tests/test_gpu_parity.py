@@ -474,6 +474,57 @@ def test_oracle_agrees_on_fresh_rays(math):
     m.destroy()
 
 
+def test_degenerate_inputs(math):
+    """What no harness should send and some will: NaN and infinite coordinates, the
+    centre of the Earth, the poles, a point 10^9 m away, zero / NaN / non-unit /
+    reversed directions -- and batches that do not fill a wave.  Same answers as
+    the reference's arithmetic (the CPU restatement), and every call returns."""
+    geo = T.c1_oracle()
+    m = B.c1_map()
+    st = B.c1_stepper(m)
+    n = 12
+    lat, lon = np.full(n, 45.5), np.full(n, 3.5)
+    pos, _ = geo.position(lat, lon, 500.0)
+    d = O.ecef_from_horizontal(lat, lon, np.full(n, 30.0), np.full(n, -5.0))
+    pos[1, 0] = np.nan
+    pos[2, 1] = np.inf
+    pos[3] = 0.0
+    pos[4] = (0.0, 0.0, 6.4e6)
+    pos[5] = (1e9, 1e9, 1e9)
+    pos[10] = (0.0, 0.0, -6.4e6)
+    d[6] = 0.0
+    d[7, 2] = np.nan
+    d[8] *= 1e6
+    d[9] *= -1.0
+    with np.errstate(all="ignore"):
+        r0, r1 = geo.step(pos.copy()), geo.step(pos.copy(), d)
+        rt = geo.trace(pos.copy(), d, max_steps=600)   # beyond 512: the per-ray lines too
+    g0, g1 = st.step(pos.copy(), None), st.step(pos.copy(), d)
+    gt = st.trace(pos.copy(), d, max_steps=600)
+    assert np.array_equal(g0["index"], r0["index"]) and np.array_equal(g1["index"], r1["index"])
+    assert np.array_equal(gt["index"], rt["index"]) and np.array_equal(gt["n_steps"], rt["n_steps"])
+    ok = np.isfinite(r1["step"])
+    assert np.array_equal(np.isfinite(g1["step"]), ok)
+    assert np.abs(g1["step"][ok] - r1["step"][ok]).max() <= 1e-6 * np.abs(r1["step"][ok]).max()
+    ok = np.isfinite(rt["length"])
+    assert np.array_equal(np.isfinite(gt["length"]), ok)
+    assert (np.abs(gt["length"][ok] - rt["length"][ok]) <= 1e-6 * np.maximum(rt["length"][ok], 1e-3)).all()
+    # ragged batches: one ray, a wave less one, a wave, a wave and one, a block and one
+    lat, lon, az, el = TA.synth.uniform_rays(257, T.C1_Y, T.C1_X, seed=5)
+    p0, _ = geo.position(lat, lon, 300.0)
+    dd = O.ecef_from_horizontal(lat, lon, az, el)
+    ref = geo.trace(p0, dd, threads=2)
+    for k in (1, 63, 64, 65, 257):
+        t = st.trace(p0[:k].copy(), dd[:k])
+        check_trace(t, ref["index"][:k], ref["length"][:k], ref["n_steps"][:k], f"{k} rays")
+        s1 = st.step(p0[:k].copy(), dd[:k])
+        o1 = geo.step(p0[:k].copy(), dd[:k])
+        assert np.array_equal(s1["index"], o1["index"])
+        assert np.abs(s1["step"] - o1["step"]).max() <= 1e-6 * o1["step"].max()
+    st.destroy()
+    m.destroy()
+
+
 @pytest.mark.parametrize("where", ["south-west", "north-80", "equator-dateline"])
 def test_long_rays_other_quadrants(where, math):
     """Grazing rays (thousands of steps: the fast trace's second phase, where

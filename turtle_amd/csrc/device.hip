@@ -345,8 +345,13 @@ __device__ __forceinline__ void f_line_build(RayLine & L, double latitude, doubl
          * fourth-order term is within 1e-21 (1 + tan^3 lat) s^4 metres */
         const double tl = fabs(S) * nu * re;
         L.c4 = 1.2e-21 * __builtin_fma(tl * tl, tl, 1.5);
-        /* not near a pole (1 / cos lat), nor where the longitude wraps */
-        L.valid = (C > 1e-3) & (fabs(longitude) < 179.9);
+        /* not near a pole (1 / cos lat), nor where the longitude wraps; and only
+         * where the bound above was measured: s is a LENGTH (a unit direction;
+         * the reference steps along any vector, and so does the closed form that
+         * a ray without a valid line keeps using), not deep inside the Earth
+         * (1 / (M + h)).  NaNs fail every test. */
+        const double dd = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
+        L.valid = (C > 1e-3) & (fabs(longitude) < 179.9) & (fabs(dd - 1.) < 1e-6) & (h > -1e5);
 }
 
 __device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
