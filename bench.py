@@ -103,6 +103,7 @@ def cpu_baseline(tiles, use_stack, n_rays, seed):
     d = O.ecef_from_horizontal(lat, lon, az, el)
     cores = host_cores()
     out = {}
+    geo.trace(pos[:20000], d[:20000], local_range=0.0, threads=cores)   # warm up
     for tag, rng in (("range0", 0.0), ("range1", 1.0)):
         t0 = time.perf_counter()
         r = geo.trace(pos, d, local_range=rng, threads=cores)
@@ -113,6 +114,24 @@ def cpu_baseline(tiles, use_stack, n_rays, seed):
     one = geo.trace(pos[: max(1, n_rays // cores)], d[: max(1, n_rays // cores)],
                     local_range=0.0, threads=1)
     out["one_core"] = one["total_steps"] / (time.perf_counter() - t0)
+    # The REAL reference, when its build travelled with the repo (oracle/_ref/, made
+    # by oracle/Makefile in the build container) and the terrain is a single map: the
+    # same rays through turtle_stepper_step in the example harness's loop
+    # (oracle/ref_driver.c), one stepper per thread; the clock runs over the stepping.
+    from oracle import ref_ffi as R
+    if (not use_stack) and R.driver_available():
+        tmp = tempfile.mkdtemp(prefix="turtle_ref_")
+        path = synth.write_hgt(tmp, lat0, lon0)
+        R.trace_map(path, pos[:20000], d[:20000], local_range=1.0, threads=cores)   # warm up
+        for tag, rng in (("ref_range1", 1.0), ("ref_range0", 0.0)):
+            a = R.trace_map(path, pos, d, local_range=rng, threads=cores)
+            out[tag] = a["total_steps"] / a["seconds"]
+        same = geo.trace(pos, d, local_range=0.0, threads=cores)
+        out["ref_equal"] = bool(np.array_equal(a["index"], same["index"]) and
+                                np.array_equal(a["length"], same["length"]))
+        a = R.trace_map(path, pos[: max(1, n_rays // cores)], d[: max(1, n_rays // cores)],
+                        local_range=1.0, threads=1)
+        out["ref_one_core"] = a["total_steps"] / a["seconds"]
     return out, cores, r
 
 
@@ -322,13 +341,25 @@ def main():
         }
         if not args.no_cpu and world == 1:
             cpu, cores, _ = cpu_baseline(tiles, use_stack, args.cpu_rays, 0x5EED2026)
-            line["cpu_baseline"] = {
-                "value": cpu["range0"], "unit": "ray-steps/s", "cores": cores,
-                "kind": "port",
-                "sample": f"{args.cpu_rays} rays of the same recipe, oracle/ C restatement, "
-                          f"{cores} pthreads, exact transform (range 0); "
-                          f"range 1: {cpu['range1']:.4g} steps/s; "
-                          f"one core: {cpu['one_core']:.4g} steps/s"}
+            port = (f"oracle/ C restatement, {cores} pthreads: {cpu['range0']:.4g} steps/s with the "
+                    f"exact transform (range 0), {cpu['range1']:.4g} at range 1, "
+                    f"{cpu['one_core']:.4g} on one core")
+            if "ref_range1" in cpu:
+                line["cpu_baseline"] = {
+                    "value": cpu["ref_range1"], "unit": "ray-steps/s", "cores": cores,
+                    "kind": "reference",
+                    "sample": f"{args.cpu_rays} rays of the same recipe through the reference itself "
+                              f"(oracle/_ref, turtle_stepper_step in the example harness's loop, one "
+                              f"stepper per thread, {cores} pthreads, its default local range of 1 m); "
+                              f"with the exact transform (range 0, what the GPU computes): "
+                              f"{cpu['ref_range0']:.4g} steps/s; one core: {cpu['ref_one_core']:.4g}; "
+                              f"results equal to the restatement's bit for bit: {cpu['ref_equal']}. "
+                              f"For comparison the {port}"}
+            else:
+                line["cpu_baseline"] = {
+                    "value": cpu["range0"], "unit": "ray-steps/s", "cores": cores,
+                    "kind": "port",
+                    "sample": f"{args.cpu_rays} rays of the same recipe, {port}"}
         print(json.dumps(line), flush=True)
 
     stepper.destroy()

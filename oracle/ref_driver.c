@@ -1,0 +1,120 @@
+/*
+ * ref_driver.c -- TEST INFRASTRUCTURE.  A harness around the REAL reference
+ * (oracle/_ref/libturtle_ref.so, compiled by oracle/Makefile from the sources
+ * under /root/reference), so that bench.py can time the reference's own CPU
+ * path beside the GPU's (cpu_baseline.kind = "reference").
+ *
+ * It is the loop of the reference's example harness [ref
+ * examples/example-stepper.c:116-140] -- sample the start point, then
+ * turtle_stepper_step until the medium changes -- over n rays, on `threads`
+ * pthreads with one stepper each (a stepper is not re-entrant [ref
+ * src/turtle/stepper.h:101-110]) sharing one read-only map.  Only the
+ * reference's PUBLIC API is used; this file contains none of its code.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "turtle.h" /* the reference's header: -I$(REF)/include, build container only */
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+struct job {
+        struct turtle_map * map;
+        double range, slope, resolution;
+        long begin, end;
+        double * position;
+        const double * direction;
+        int max_steps;
+        int * index;
+        double * length;
+        int * n_steps;
+        long steps;
+        int failed;
+};
+
+static void * worker(void * arg)
+{
+        struct job * job = arg;
+        struct turtle_stepper * stepper = NULL;
+        if ((turtle_stepper_create(&stepper) != TURTLE_RETURN_SUCCESS) ||
+            (turtle_stepper_add_map(stepper, job->map, 0.) != TURTLE_RETURN_SUCCESS)) {
+                job->failed = 1;
+                return NULL;
+        }
+        turtle_stepper_range_set(stepper, job->range);
+        turtle_stepper_slope_set(stepper, job->slope);
+        turtle_stepper_resolution_set(stepper, job->resolution);
+        long r;
+        for (r = job->begin; r < job->end; r++) {
+                double * pos = job->position + 3 * r;
+                const double * dir = job->direction + 3 * r;
+                int idx[2];
+                double total = 0.;
+                int n = 0;
+                turtle_stepper_step(stepper, pos, NULL, NULL, NULL, NULL, NULL, NULL, idx);
+                const int medium = idx[0];
+                if (medium >= 0) {
+                        while (n < job->max_steps) {
+                                double ds;
+                                turtle_stepper_step(
+                                    stepper, pos, dir, NULL, NULL, NULL, NULL, &ds, idx);
+                                total += ds;
+                                n++;
+                                if (idx[0] != medium) break;
+                        }
+                }
+                if (job->index != NULL) job->index[2 * r] = idx[0], job->index[2 * r + 1] = idx[1];
+                if (job->length != NULL) job->length[r] = total;
+                if (job->n_steps != NULL) job->n_steps[r] = n;
+                job->steps += n;
+        }
+        turtle_stepper_destroy(&stepper);
+        return NULL;
+}
+
+/* Traces n rays through the map at `map_path` (any format the reference loads
+ * without external libraries: .hgt).  Returns the total number of steps, or -1. */
+long ref_trace_map_n(const char * map_path, double range, double slope, double resolution,
+    long n, double * position, const double * direction, int max_steps, int * index,
+    double * length, int * n_steps, int threads, double * seconds /* of the stepping alone */)
+{
+        turtle_error_handler_set(NULL); /* return codes, no exit() */
+        struct turtle_map * map = NULL;
+        if (turtle_map_load(&map, map_path) != TURTLE_RETURN_SUCCESS) return -1;
+        if (threads < 1) threads = 1;
+        struct job * jobs = calloc((size_t)threads, sizeof(*jobs));
+        pthread_t * tid = calloc((size_t)threads, sizeof(*tid));
+        long steps = -1;
+        if ((jobs != NULL) && (tid != NULL)) {
+                int t;
+                for (t = 0; t < threads; t++) {
+                        struct job * j = &jobs[t];
+                        j->map = map, j->range = range, j->slope = slope, j->resolution = resolution;
+                        j->begin = n * t / threads, j->end = n * (t + 1) / threads;
+                        j->position = position, j->direction = direction;
+                        j->max_steps = max_steps;
+                        j->index = index, j->length = length, j->n_steps = n_steps;
+                }
+                struct timespec t0, t1;
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                if (threads == 1)
+                        worker(&jobs[0]);
+                else {
+                        for (t = 0; t < threads; t++) pthread_create(&tid[t], NULL, worker, &jobs[t]);
+                        for (t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+                }
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if (seconds != NULL)
+                        *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+                steps = 0;
+                for (t = 0; t < threads; t++) {
+                        steps += jobs[t].steps;
+                        if (jobs[t].failed) steps = -1;
+                }
+        }
+        free(jobs);
+        free(tid);
+        turtle_map_destroy(&map);
+        return steps;
+}

@@ -325,3 +325,35 @@ class RefProjection:
 
     def destroy(self):
         lib().turtle_projection_destroy(C.byref(self.h))
+
+
+# ---- the timing harness (oracle/ref_driver.c) --------------------------------
+
+DRIVER_PATH = os.path.join(HERE, "_ref", "libturtle_ref_driver.so")
+
+
+def driver_available() -> bool:
+    return os.path.exists(DRIVER_PATH) and os.path.exists(LIB_PATH)
+
+
+def trace_map(map_path, position, direction, local_range=1.0, slope=0.4, resolution=1e-2,
+              max_steps=100000, threads=1):
+    """n rays through the map at `map_path`, stepped by the REAL reference until
+    their medium changes (the example harness's loop), `threads` pthreads."""
+    L = C.CDLL(DRIVER_PATH)
+    L.ref_trace_map_n.restype = C.c_long
+    pos = np.array(position, dtype=np.float64, order="C").reshape(-1, 3)
+    dire = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+    n = pos.shape[0]
+    index = np.empty((n, 2), dtype=np.int32)
+    length = np.empty(n, dtype=np.float64)
+    nsteps = np.empty(n, dtype=np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    seconds = C.c_double(0.0)   # the stepping alone: the map is loaded before the clock starts
+    total = L.ref_trace_map_n(os.fsencode(map_path), D(local_range), D(slope), D(resolution),
+                              C.c_long(n), vp(pos), vp(dire), C.c_int(max_steps), vp(index),
+                              vp(length), vp(nsteps), C.c_int(threads), C.byref(seconds))
+    if total < 0:
+        raise RuntimeError(f"the reference could not load {map_path}")
+    return dict(position=pos, index=index, length=length, n_steps=nsteps, total_steps=int(total),
+                seconds=seconds.value)
