@@ -47,3 +47,9 @@ for k in (1, 8, 64, 512, 4096):
 mid = order[len(order) // 2: len(order) // 2 + 1]
 ms, longest, total = timed(mid)
 print(f"a median ray alone: {ms:.3f} ms, {longest} steps -> {1e3 * ms / longest:.3f} us per step")
+# rays of 1 500 - 2 500 steps (the ones phase B waits for), alone and a few to a wave
+medium = order[(steps[order] <= 2500) & (steps[order] >= 1500)]
+for k in (1, 8, 64, 1024):
+    if medium.size >= k:
+        ms, longest, total = timed(medium[:k])
+        print(f"{k:5d} medium rays alone: {ms:7.3f} ms, longest {longest} steps -> {1e3 * ms / longest:.3f} us per step of the longest")

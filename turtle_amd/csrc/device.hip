@@ -1695,6 +1695,7 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
 constexpr int kChunk = 64; /* rays a wave draws from the global queue at once */
 constexpr int kTailChunk = 8; /* ... in the last phase of a fast trace: few, and long */
 constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many live lanes */
+constexpr int kCreepUnroll = 4; /* steps per trip of the one-map creep loop */
 
 enum { ST_INIT = 0, ST_STEP = 1, ST_BISECT = 2 };
 
@@ -1893,7 +1894,15 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
 
                 /* The single-map case gets a leaner body still: only the line and
                  * the cached cell (no closed form, no fetch inside; a lane that
-                 * needs either leaves for one general iteration). */
+                 * needs either leaves for one general iteration).  What a launch
+                 * waits for in the end is ONE ray -- C2's longest takes 11 326 steps,
+                 * most of them here, alone in its wave -- so what counts is the
+                 * latency of a trip, and a good part of that is the wave-wide
+                 * question "does any lane have to leave?" (compare, ballot, branch:
+                 * the vector and scalar units wait for each other).  It is asked once
+                 * per kCreepUnroll steps: a lane that cannot take one of them takes
+                 * none of the following either (nothing is committed from there on),
+                 * and the wave leaves after the group. */
                 if (MODEL && (MODE == TAMD_MODE_ONE_MAP) &&
                     (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
                         const tamd_grid & g = ctx.grid;
@@ -1902,38 +1911,40 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 /* no short-circuits below: every lane computes
                                  * everything (garbage is harmless, nothing is
                                  * committed on failure) and the tests are AND-ed */
-                                const double sl = line.s + ds;
-                                double lat, lon, alt;
-                                f_line_eval(line, sl, lat, lon, alt);
-                                /* f_grid_locate without its rim fallback: a point
-                                 * within 1e-6 cell of the rim leaves the loop */
-                                CellAt c;
-                                c.hx = (lon - g.x0) * g.inv_dx;
-                                c.hy = (lat - g.y0) * g.inv_dy;
-                                const bool interior =
-                                    (c.hx > 1e-6) & (c.hx < mx) & (c.hy > 1e-6) & (c.hy < my);
-                                c.ix = min(max((int)c.hx, 0), g.nx - 2);
-                                c.iy = min(max((int)c.hy, 0), g.ny - 2);
-                                c.id = (unsigned)c.iy * (unsigned)g.nx + (unsigned)c.ix;
-                                const double elevation =
-                                    f_grid_blend(g, c, cell.lo, cell.hi) + ctx.offset;
-                                const double clearance = fabs(alt - elevation);
-                                const int mm = (elevation >= alt) ? 0 : 1;
-                                const bool ok = (ray >= 0) & (state == ST_STEP) & lined_ &
-                                    (count + 1 < max_steps) & line.valid & (fabs(sl) <= kLineRange) &
-                                    f_line_serves(line, sl, clearance) & interior &
-                                    (c.id == cell.id) & (mm == m);
-                                if (__ballot((ray >= 0) & !ok) != 0) break;
-                                if (ok) {
-                                        line.s = sl;
-                                        len += ds;
-                                        count++;
-                                        my_samples++;
+                                bool going = (ray >= 0) & (state == ST_STEP) & lined_ & line.valid;
+#pragma unroll
+                                for (int u = 0; u < kCreepUnroll; u++) {
+                                        const double sl = line.s + ds;
+                                        double lat, lon, alt;
+                                        f_line_eval(line, sl, lat, lon, alt);
+                                        /* f_grid_locate without its rim fallback: a point
+                                         * within 1e-6 cell of the rim leaves the loop */
+                                        CellAt c;
+                                        c.hx = (lon - g.x0) * g.inv_dx;
+                                        c.hy = (lat - g.y0) * g.inv_dy;
+                                        const bool interior =
+                                            (c.hx > 1e-6) & (c.hx < mx) & (c.hy > 1e-6) & (c.hy < my);
+                                        c.ix = min(max((int)c.hx, 0), g.nx - 2);
+                                        c.iy = min(max((int)c.hy, 0), g.ny - 2);
+                                        c.id = (unsigned)c.iy * (unsigned)g.nx + (unsigned)c.ix;
+                                        const double elevation =
+                                            f_grid_blend(g, c, cell.lo, cell.hi) + ctx.offset;
+                                        const double clearance = fabs(alt - elevation);
+                                        const int mm = (elevation >= alt) ? 0 : 1;
+                                        going = going & (count + 1 < max_steps) & (fabs(sl) <= kLineRange) &
+                                            f_line_serves(line, sl, clearance) & interior &
+                                            (c.id == cell.id) & (mm == m);
                                         /* d_step_length for one surface: both of its
                                          * cases are |alt - elevation| */
-                                        ds = clearance * v.slope;
-                                        if (ds < v.resolution) ds = v.resolution;
+                                        double ds_next = clearance * v.slope;
+                                        if (ds_next < v.resolution) ds_next = v.resolution;
+                                        line.s = going ? sl : line.s;
+                                        len = going ? len + ds : len;
+                                        count += going ? 1 : 0;
+                                        my_samples += going ? 1 : 0;
+                                        ds = going ? ds_next : ds;
                                 }
+                                if (__ballot((ray >= 0) & !going) != 0) break;
                         }
                 }
 
