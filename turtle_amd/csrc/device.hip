@@ -1907,6 +1907,26 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                     (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
                         const tamd_grid & g = ctx.grid;
                         const double mx = (double)(g.nx - 1) - 1e-6, my = (double)(g.ny - 1) - 1e-6;
+                        /* The cached cell, decoded once per entry: its node coordinates
+                         * as doubles and its four elevations -- a trip then needs no
+                         * conversion between integers and doubles (a quarter of the
+                         * rate of the other instructions, and on the chain).  Same
+                         * values as f_grid_locate / f_grid_blend produce: for an
+                         * interior point (double)(int)hx == trunc(hx), and the clamp of
+                         * the cell index does nothing. */
+                        const unsigned cell_iy = (cell.id != ~0u) ? cell.id / (unsigned)g.nx : 0u;
+                        const double cy = (cell.id != ~0u) ? (double)cell_iy : -1.;
+                        const double cx = (cell.id != ~0u) ? (double)(cell.id - cell_iy * (unsigned)g.nx) : -1.;
+                        double z00, z10, z01, z11;
+                        if (g.is_signed) {
+                                z00 = (double)(int16_t)(cell.lo & 0xffffu), z10 = (double)((int)cell.lo >> 16);
+                                z01 = (double)(int16_t)(cell.hi & 0xffffu), z11 = (double)((int)cell.hi >> 16);
+                        } else {
+                                z00 = (double)(cell.lo & 0xffffu), z10 = (double)(cell.lo >> 16);
+                                z01 = (double)(cell.hi & 0xffffu), z11 = (double)(cell.hi >> 16);
+                        }
+                        z00 = __builtin_fma(z00, g.dz, g.z0), z10 = __builtin_fma(z10, g.dz, g.z0);
+                        z01 = __builtin_fma(z01, g.dz, g.z0), z11 = __builtin_fma(z11, g.dz, g.z0);
                         for (int it = 0; it < 4096; it++) {
                                 /* no short-circuits below: every lane computes
                                  * everything (garbage is harmless, nothing is
@@ -1919,21 +1939,22 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         f_line_eval(line, sl, lat, lon, alt);
                                         /* f_grid_locate without its rim fallback: a point
                                          * within 1e-6 cell of the rim leaves the loop */
-                                        CellAt c;
-                                        c.hx = (lon - g.x0) * g.inv_dx;
-                                        c.hy = (lat - g.y0) * g.inv_dy;
+                                        const double hx = (lon - g.x0) * g.inv_dx;
+                                        const double hy = (lat - g.y0) * g.inv_dy;
                                         const bool interior =
-                                            (c.hx > 1e-6) & (c.hx < mx) & (c.hy > 1e-6) & (c.hy < my);
-                                        c.ix = min(max((int)c.hx, 0), g.nx - 2);
-                                        c.iy = min(max((int)c.hy, 0), g.ny - 2);
-                                        c.id = (unsigned)c.iy * (unsigned)g.nx + (unsigned)c.ix;
+                                            (hx > 1e-6) & (hx < mx) & (hy > 1e-6) & (hy < my);
+                                        const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);
+                                        /* f_grid_blend */
+                                        const double fx = hx - tx, fy = hy - ty;
+                                        const double gx = 1. - fx, gy = 1. - fy;
                                         const double elevation =
-                                            f_grid_blend(g, c, cell.lo, cell.hi) + ctx.offset;
+                                            (z00 * gx * gy + z01 * gx * fy + z10 * fx * gy + z11 * fx * fy) +
+                                            ctx.offset;
                                         const double clearance = fabs(alt - elevation);
                                         const int mm = (elevation >= alt) ? 0 : 1;
                                         going = going & (count + 1 < max_steps) & (fabs(sl) <= kLineRange) &
                                             f_line_serves(line, sl, clearance) & interior &
-                                            (c.id == cell.id) & (mm == m);
+                                            (tx == cx) & (ty == cy) & (mm == m);
                                         /* d_step_length for one surface: both of its
                                          * cases are |alt - elevation| */
                                         double ds_next = clearance * v.slope;
