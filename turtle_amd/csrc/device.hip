@@ -22,8 +22,11 @@
  *   k_elevation     batch bilinear lookup, map/stack   [ref map.c:229-277, stack.c:300-361]
  *   k_position      batch turtle_stepper_position      [ref stepper.c:877-931]
  *   k_step          batch turtle_stepper_step [ref stepper.c:780-875]: the sample and
- *                   the tentative step; rays that crossed a boundary are listed
+ *   k_step_fast     the tentative step; rays that crossed a boundary are listed
+ *                   (k_step_fast: the fast-math body of the one-map / one-stack
+ *                   modes held to 128 registers)
  *   k_bisect        ... and bisected here, packed [ref stepper.c:836-864]
+ *   k_gradient, k_project   batch gradients and map projections
  *   k_trace         persistent-wave trace-to-boundary loop (the hot kernel)
  *   k_isotropic     Philox-4x32-10 isotropic directions (scattering harness)
  *   k_tally         hit counts + path-length histogram (uint64, exact)
