@@ -249,8 +249,8 @@ def main():
             TA.isotropic(n, 0x5EED2026, k, first_ray, out=direction_k)
             inside = state["index"][:, 0] >= 0
             state = stepper.step(state["position"], direction_k, resume=state)
-            moved += inside.to(torch.int32)
-            total += state["step"]
+            moved.add_(inside)
+            total.add_(state["step"])
         index.copy_(state["index"])
         length.copy_(total)
         nsteps.copy_(moved)
