@@ -1861,6 +1861,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                  * the same values as the general path, so results do not depend
                  * on whether it engaged. */
                 if (MODEL && (MODE != TAMD_MODE_ONE_MAP) &&
+                    !((MODE == TAMD_MODE_ONE_STACK) && ctx.stack.regular) && /* -> the lean loop below */
                     (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
                         for (int it = 0; it < 4096; it++) {
                                 bool fail = false;
@@ -1906,10 +1907,24 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                  * per kCreepUnroll steps: a lane that cannot take one of them takes
                  * none of the following either (nothing is committed from there on),
                  * and the wave leaves after the group. */
-                if (MODEL && (MODE == TAMD_MODE_ONE_MAP) &&
+                if (MODEL &&
+                    ((MODE == TAMD_MODE_ONE_MAP) || ((MODE == TAMD_MODE_ONE_STACK) && ctx.stack.regular)) &&
                     (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
-                        const tamd_grid & g = ctx.grid;
-                        const double mx = (double)(g.nx - 1) - 1e-6, my = (double)(g.ny - 1) - 1e-6;
+                        /* one map: the grid.  A regular stack: the tile the cached cell is
+                         * in -- the shared tile shape at that tile's origin, computed as
+                         * f_stack_elevation computes it; a point `interior` to it (same
+                         * guard as there) gets that tile from the directory too */
+                        constexpr bool STACK = (MODE == TAMD_MODE_ONE_STACK);
+                        const tamd_grid & g = STACK ? ctx.stack.proto : ctx.grid;
+                        constexpr double guard = STACK ? kSeamGuard : 1e-6;
+                        const double mx = (double)(g.nx - 1) - guard, my = (double)(g.ny - 1) - guard;
+                        const bool cached = (cell.id != ~0u);
+                        const unsigned slot = STACK ? (cell.id >> 24) : 0u;
+                        const unsigned cell_index = STACK ? (cell.id & 0xffffffu) : cell.id;
+                        const unsigned tile_y = STACK ? slot / (unsigned)ctx.stack.nlon : 0u;
+                        const unsigned tile_x = STACK ? slot - tile_y * (unsigned)ctx.stack.nlon : 0u;
+                        const double x0 = STACK ? ctx.stack.lon0 + (int)tile_x * ctx.stack.dlon : g.x0;
+                        const double y0 = STACK ? ctx.stack.lat0 + (int)tile_y * ctx.stack.dlat : g.y0;
                         /* The cached cell, decoded once per entry: its node coordinates
                          * as doubles and its four elevations -- a trip then needs no
                          * conversion between integers and doubles (a quarter of the
@@ -1917,9 +1932,9 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                          * values as f_grid_locate / f_grid_blend produce: for an
                          * interior point (double)(int)hx == trunc(hx), and the clamp of
                          * the cell index does nothing. */
-                        const unsigned cell_iy = (cell.id != ~0u) ? cell.id / (unsigned)g.nx : 0u;
-                        const double cy = (cell.id != ~0u) ? (double)cell_iy : -1.;
-                        const double cx = (cell.id != ~0u) ? (double)(cell.id - cell_iy * (unsigned)g.nx) : -1.;
+                        const unsigned cell_iy = cached ? cell_index / (unsigned)g.nx : 0u;
+                        const double cy = cached ? (double)cell_iy : -1.;
+                        const double cx = cached ? (double)(cell_index - cell_iy * (unsigned)g.nx) : -1.;
                         double z00, z10, z01, z11;
                         if (g.is_signed) {
                                 z00 = (double)(int16_t)(cell.lo & 0xffffu), z10 = (double)((int)cell.lo >> 16);
@@ -1942,10 +1957,10 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         f_line_eval(line, sl, lat, lon, alt);
                                         /* f_grid_locate without its rim fallback: a point
                                          * within 1e-6 cell of the rim leaves the loop */
-                                        const double hx = (lon - g.x0) * g.inv_dx;
-                                        const double hy = (lat - g.y0) * g.inv_dy;
+                                        const double hx = (lon - x0) * g.inv_dx;
+                                        const double hy = (lat - y0) * g.inv_dy;
                                         const bool interior =
-                                            (hx > 1e-6) & (hx < mx) & (hy > 1e-6) & (hy < my);
+                                            (hx > guard) & (hx < mx) & (hy > guard) & (hy < my);
                                         const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);
                                         /* f_grid_blend */
                                         const double fx = hx - tx, fy = hy - ty;
