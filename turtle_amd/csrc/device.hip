@@ -2685,11 +2685,16 @@ static int park_threshold_2(void)
         if (value < 0) value = max(0, env_int("TURTLE_AMD_PARK2", 0));
         return value;
 }
-static int creep_lanes(void)
+/* Few in a small batch, where the launch waits for single rays in all-but-empty
+ * waves (C2, 1 M rays: 8 lanes 6.85 ms, 32 lanes 7.08, 64 lanes 7.4); more in a large
+ * one, where phase B is a matter of throughput (C2 at 4 M rays: 20.5 -> 19.6 ms with 32;
+ * C3, 10 M: 42.6 -> 41.8).  The loop gives the same bits whenever it engages. */
+static int creep_lanes(long n)
 {
-        static int value = -1;
-        if (value < 0) value = env_int("TURTLE_AMD_CREEP_LANES", kCreepLanes);
-        return value;
+        static int value = -2;
+        if (value == -2) value = env_int("TURTLE_AMD_CREEP_LANES", -1);
+        if (value >= 0) return value;
+        return (n >= 2000000) ? 4 * kCreepLanes : kCreepLanes;
 }
 static int drain_lanes(void)
 {
@@ -2719,7 +2724,7 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         const bool again = (pg.ids != nullptr);
         if (again) flags |= TRACE_CARRY_MEDIUM;
         const int resume = again ? 2 : 0;
-        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, resume, pg, 0, 0, kChunk, creep_lanes() };
+        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, resume, pg, 0, 0, kChunk, creep_lanes(n) };
         if (g_math_strict || !view.fast_ok)
                 return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
@@ -2733,17 +2738,17 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         int park2 = park_threshold_2();
         if ((park2 <= park) || (max_steps <= park2)) park2 = 0;
         const PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, resume, pg, drain_lanes(), 0,
-                kChunk, creep_lanes() };
+                kChunk, creep_lanes(n) };
         if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
                 n_steps, flags, a, stats, queue))
                 return 1;
         const PhaseIO b = { parked, queue + 2, park2 ? parked + n : nullptr, queue + 4, park2, 1, pg,
-                0, park, kChunk, creep_lanes() };
+                0, park, kChunk, creep_lanes(n) };
         if (launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
                 n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1))
                 return 1;
         if (park2 == 0) return 0;
-        const PhaseIO c = { parked + n, queue + 4, nullptr, nullptr, 0, 1, pg, 0, park, kTailChunk, creep_lanes() };
+        const PhaseIO c = { parked + n, queue + 4, nullptr, nullptr, 0, 1, pg, 0, park, kTailChunk, creep_lanes(n) };
         return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
             n_steps, flags | TRACE_CARRY_MEDIUM, c, stats, queue + 3);
 }
