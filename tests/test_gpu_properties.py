@@ -1,6 +1,8 @@
 """Parity at the BASELINE sizes (C2: 1 M rays through the 3601^2 tile), where
 the reference's outputs are not stored: the CPU restatement on all host cores
 is the checker, plus size-independent properties of a trace."""
+import os
+
 import numpy as np
 import pytest
 
@@ -100,3 +102,27 @@ def test_c2_properties(c2):
     h1, g1 = TA.tally(a["index"], a["length"], 2, 1024, 65536.0)
     h2, g2 = TA.tally(b["index"], b["length"], 2, 1024, 65536.0, h1, g1)
     assert np.array_equal(hits, h2) and np.array_equal(hist, g2) and hits.sum() == N
+
+
+def test_creep_loop_changes_no_bit(tmp_path):
+    """The lean loops of phase B take the samples the general
+    iteration would take, with the same functions on the same values: a batch with
+    thousands-of-steps rays gives the same bits with the loops off
+    (TURTLE_AMD_CREEP_LANES=0), at their default, and engaging at any number of
+    live lanes (64) -- through one map and through a regular stack."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    results = {}
+    for lanes in ("0", "8", "64"):
+        out = os.path.join(tmp_path, f"lanes{lanes}.npz")
+        work = os.path.join(tmp_path, f"work{lanes}")
+        env = dict(os.environ, TURTLE_AMD_CREEP_LANES=lanes)
+        subprocess.run([sys.executable, os.path.join(here, "creep_probe.py"), out, work],
+                       check=True, env=env, timeout=300)
+        results[lanes] = dict(np.load(out))
+    base = results["0"]
+    assert base["map_n_steps"].max() > 2000 and base["stack_n_steps"].max() > 2000
+    for lanes in ("8", "64"):
+        for key, ref in base.items():
+            assert np.array_equal(results[lanes][key], ref), (lanes, key)
