@@ -256,12 +256,31 @@ __device__ __forceinline__ double f_atan2(double y, double x)
  * serves ~1000 samples.  Whether a sample comes from the line depends on the
  * ray alone (its own line and path parameter), never on its wave. */
 constexpr double kLineRange = 4000.; /* m, either side of the origin: hard limit */
-constexpr double kLineTolerance = 2e-10; /* see f_line_serves */
+constexpr double kLineTolerance = 2e-10; /* see f_line_accurate */
+/* A ray's position is ACCUMULATED step by step, B += d * ds with the reference's
+ * roundings [ref stepper.c:824, :862-863], in every phase: each step leaves B
+ * up to half an ulp of 6.4e6 m per coordinate (8e-10 m) off the straight line,
+ * mostly the same way from step to step (a skimming ray adds the same increment
+ * thousands of times: 2.7e-6 m measured over the 11 326 steps of C2's longest
+ * ray) -- and the reference decides on ITS positions.  The line is a function of
+ * the path length alone, so a sample taken from it answers for the ideal point
+ * O + d * s, which is off the reference's by that drift.  That is harmless where
+ * it only sizes the next step, and decisive where the medium is decided within
+ * the drift of the boundary (a ray tangent to the ground: one step more or
+ * less is 1e-2 m of path).  So the line keeps count of what its origin's
+ * closed form, its truncation and the drift since it was laid can amount to
+ * (tau: kLineTau0 at the origin + kLineDrift per accepted step), and a sample
+ * whose clearance is not above it is taken again by the closed form AT THE
+ * ACCUMULATED POSITION, as phase A would: every medium decision is then the
+ * closed form's, to well below its own noise. */
+constexpr double kLineTau0 = 1e-8;  /* m: 3 x the closed form's own bound (3e-9 m) */
+constexpr double kLineDrift = 1e-9; /* m per step: (3 x (2^-31)^2)^0.5 = 8.1e-10 rounded up */
 
 struct RayLine {
         double s;                /* path parameter of the ray's position B */
         double lat[4], lon[4], alt[4]; /* degrees, degrees, metres; [k]: s^k */
         double c4;               /* bound on the neglected term: c4 s^4 metres */
+        double tau;              /* clearance below which the closed form decides (above) */
         bool valid;
 };
 
@@ -271,10 +290,16 @@ struct RayLine {
  * from any boundary, below 2e-10 OF the clearance: all such a sample decides
  * is the length of the next step, to the same relative accuracy.  At latitude
  * 45 this lets a line serve 500 m near the ground and ~2 km in free flight. */
-__device__ __forceinline__ bool f_line_serves(const RayLine & L, double s, double clearance)
+__device__ __forceinline__ bool f_line_accurate(const RayLine & L, double s, double clearance)
 {
         const double s2 = s * s;
         return L.c4 * s2 * s2 <= kLineTolerance * fmax(clearance, 1.);
+}
+
+/* ... and the sample is not within the line's drift of a boundary (kLineTau0) */
+__device__ __forceinline__ bool f_line_serves(const RayLine & L, double s, double clearance)
+{
+        return f_line_accurate(L, s, clearance) & (clearance > L.tau);
 }
 
 __device__ __forceinline__ void f_line_eval(const RayLine & L, double s, double & latitude,
@@ -344,6 +369,7 @@ __device__ __forceinline__ void f_line_build(RayLine & L, double latitude, doubl
         L.lon[2] = (0.5 * kRad2Deg) * l2, L.lon[3] = (kRad2Deg / 6.) * l3;
         L.alt[0] = h, L.alt[1] = h1, L.alt[2] = 0.5 * h2, L.alt[3] = h3 * (1. / 6.);
         L.s = 0.;
+        L.tau = kLineTau0;
         /* measured (40-digit reference, any direction, h <= 9 km): the
          * fourth-order term is within 1e-21 (1 + tan^3 lat) s^4 metres */
         const double tl = fabs(S) * nu * re;
@@ -359,7 +385,7 @@ __device__ __forceinline__ void f_line_build(RayLine & L, double latitude, doubl
 
 __device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
     double & latitude, double & longitude, double & altitude, RayLine * build = nullptr,
-    double dx = 0., double dy = 0., double dz = 0.)
+    double dx = 0., double dy = 0., double dz = 0., bool lay = true /* build: only if */)
 {
         constexpr double kRad2Deg = 57.29577951308232;
         const double a = kA;
@@ -375,7 +401,7 @@ __device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
                 latitude = (z >= 0.) ? 90. : -90.;
                 longitude = 0.;
                 altitude = fabs(z) - kB;
-                if (build != nullptr) build->valid = false;
+                if ((build != nullptr) && lay) build->valid = false;
                 return;
         }
 
@@ -425,7 +451,7 @@ __device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
         latitude = la * kRad2Deg;
         altitude = __builtin_fma(0.5 * m, p, f);
 
-        if (build != nullptr) { /* everything it needs is at hand */
+        if ((build != nullptr) && lay) { /* everything it needs is at hand */
                 /* sine and cosine of the corrected latitude, and the radii there:
                  * p is ~4e-8 rad, which the radii of the seed would turn into
                  * 4e-10 of the distance along the line (2e-7 m at 500 m) */
@@ -1124,27 +1150,32 @@ __device__ __forceinline__ void d_sample(const tamd_view & v, const OneCtx & ctx
         d_classify<MODE, FAST>(v, ctx, s, cache);
 }
 
-/* A sample of a ray that carries a line: at (x, y, z), which is parameter sl
- * of the line.  Taken from the line if it serves; else by the closed form,
- * which lays a new line through the point (origin there: the caller re-bases
- * its path parameter).  Returns true in that case.  Which of the two happens
- * depends on the ray's own line and sample only. */
+/* A sample of a ray that carries a line: at (x, y, z) -- the ray's accumulated
+ * position, moved by the tentative length -- which is parameter sl of the line.
+ * Taken from the line if it serves.  Else by the closed form at (x, y, z): if the
+ * line is out of its range or of its accuracy there, that lays a new line
+ * through the point (origin there: the caller re-bases its path parameter) and
+ * true is returned; if the line is fine but the sample came out within its drift
+ * of a boundary (f_line_serves) the line stays.  Which of these happens
+ * depends on the ray's own line, position and sample only. */
 template <int MODE>
 __device__ __forceinline__ bool f_sample_on_line(const tamd_view & v, const OneCtx & ctx,
     double x, double y, double z, double dx, double dy, double dz, RayLine & line, double sl,
     Sample & s, CellCache * cache)
 {
-        bool serves = line.valid && (fabs(sl) <= kLineRange);
-        if (serves) {
+        bool lay = !(line.valid && (fabs(sl) <= kLineRange)), again = lay;
+        if (!lay) {
                 f_line_eval(line, sl, s.lat, s.lon, s.alt);
                 d_classify<MODE, true>(v, ctx, s, cache);
-                serves = f_line_serves(line, sl, fmin(fabs(s.alt - s.e0), fabs(s.alt - s.e1)));
+                const double clearance = fmin(fabs(s.alt - s.e0), fabs(s.alt - s.e1));
+                lay = !f_line_accurate(line, sl, clearance);
+                again = lay | !(clearance > line.tau);
         }
-        if (!serves) {
-                f_to_geodetic(x, y, z, s.lat, s.lon, s.alt, &line, dx, dy, dz);
+        if (again) {
+                f_to_geodetic(x, y, z, s.lat, s.lon, s.alt, &line, dx, dy, dz, lay);
                 d_classify<MODE, true>(v, ctx, s, cache);
         }
-        return !serves;
+        return lay;
 }
 
 /* [ref stepper.c:799-813] tentative step length from the last sample */
@@ -1696,7 +1727,6 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
 /* ---- the hot kernel ---------------------------------------------------- */
 
 constexpr int kChunk = 64; /* rays a wave draws from the global queue at once */
-constexpr int kTailChunk = 8; /* ... in the last phase of a fast trace: few, and long */
 constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many live lanes */
 constexpr int kCreepUnroll = 4; /* steps per trip of the one-map creep loop */
 
@@ -1732,27 +1762,37 @@ enum { ST_INIT = 0, ST_STEP = 1, ST_BISECT = 2 };
  * resumed after a boundary, or after parking) */
 enum { TRACE_CARRY_MEDIUM = 1 };
 
-/* Two-phase launches.  Steps per ray are heavy-tailed (C2: median 163, max
+/* Launches in passes.  Steps per ray are heavy-tailed (C2: median 163, max
  * 11 327) and a ray's samples are sequential, so a launch lasts as long as its
- * longest ray.  Phase A therefore PARKS any ray that reaches `park_after` steps
- * (its state goes back to the ray arrays, its id to a list) and phase B resumes
- * the parked rays, packed into few waves that run alone on their SIMDs, with
- * each ray's line (MODEL; see RayLine) that makes a creeping ray's sample ~7x cheaper.
+ * last ray: one that STARTS late and is long decides.  A fast trace is therefore
+ * cut two ways (run_trace):
+ *  - in TIME SLICES: a closed-form pass steps a ray for at most `quantum` steps,
+ *    then the ray goes back to the arrays and on a list (`parked`), and the next
+ *    pass takes the list.  Every ray thus takes its k-th hundred of steps before
+ *    any ray takes its (k+1)-th: no ray is still at its first steps when the
+ *    others are done, whatever its place in the caller's order.
+ *  - by ARITHMETIC: a ray that reaches `line_after` steps goes on the `lined`
+ *    list; the last pass (MODEL) takes those to the end on their lines (see
+ *    RayLine), ~7x cheaper per sample, in waves that hold nothing else.
  * Which arithmetic a sample uses depends only on the ray's own step count and
- * positions, never on scheduling: results stay deterministic. */
+ * positions, never on scheduling; a ray that changes pass is sampled again where
+ * it stands, by the same arithmetic as the sample it was handed over with:
+ * results stay deterministic. */
 struct PhaseIO {
-        const int * ids;     /* phase B: the parked ray ids (else NULL: slot == ray) */
-        const ull * n_dev;   /* phase B: their number, on the device */
-        int * parked;        /* phase A: where to list parked rays (or NULL) */
+        const int * ids;     /* the rays of this pass (NULL: slot == ray, all of them) */
+        const ull * n_dev;   /* ... and their number, on the device */
+        int * parked;        /* where to list the rays that go on in the next closed-form pass */
         ull * n_parked;
-        int park_after;      /* hand a ray over to the next phase at this step count (<= 0: never) */
-        int accumulate;      /* 1 (phase B): length / n_steps continue from the arrays; 2 (a
-                              * later round of a paged geometry): the tentative step too */
+        int * lined;         /* where to list the rays that reached line_after steps */
+        ull * n_lined;
+        int quantum;         /* steps a ray takes in this pass before it is parked (<= 0: no limit) */
+        int accumulate;      /* 1: length / n_steps continue from the arrays; 2 (a later
+                              * round of a paged geometry): the tentative step too */
         Paging pg;           /* where to list the rays that need a tile paged in (or NULLs) */
-        int drain_lanes;     /* phase A: hand over when the queue is dry and the wave is down
-                              * to this many rays */
-        int line_after;      /* phases B, C: the step count from which a ray steps on its
-                              * line (see LINED) */
+        int drain_lanes;     /* closed-form passes: hand over when the queue is dry and the
+                              * wave is down to this many rays (0: never) */
+        int line_after;      /* the step count from which a ray steps on its line (see
+                              * LINED); <= 0: never (single-pass launches) */
         int chunk;           /* rays a wave draws from the queue at once */
         int creep_lanes;     /* the creep loop engages at or below this many live lanes */
 };
@@ -1764,14 +1804,11 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
     int flags, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
 {
         if (ph.n_dev != nullptr) n = (long)*ph.n_dev;
-        /* MODEL: the position is kept as a path length on the ray's line, B = O +
-         * d * line.s with O (in bx, by, bz) the point where the line was laid,
-         * instead of being accumulated step by step [ref stepper.c:826-830]: over
-         * the thousands of steps of the rays that reach phase B the accumulated
-         * B drifts off the ray by microns (1e-9 m of rounding per step), and
-         * line and position must agree on where a sample is */
+        /* MODEL: besides its accumulated position B (bx, by, bz: the reference's
+         * roundings, in every phase: see kLineTau0) a ray on its line carries
+         * line.s, the path length from the point where the line was laid to B */
         RayLine line;
-        line.valid = false, line.s = 0.;
+        line.valid = false, line.s = 0., line.tau = kLineTau0;
         /* Which arithmetic a sample uses depends on the ray's step count alone:
          * below ph.line_after the closed form at the accumulated position, as in
          * phase A; from there on the ray's line.  Phase A can then hand a ray over
@@ -1827,7 +1864,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         if (need && (rank < avail)) {
                                 ray = pool_next + rank;
                                 if (ph.ids != nullptr) ray = ph.ids[ray];
-                                if (MODEL) line.valid = false, line.s = 0.;
+                                if (MODEL) line.valid = false, line.s = 0., line.tau = kLineTau0;
                                 bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
                                 dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
                                 len = 0., count = 0, state = ST_INIT;
@@ -1871,13 +1908,12 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         fail = (state != ST_STEP) || (count + 1 >= max_steps) || !lined_;
                                         if (!fail) {
                                                 const double sl = line.s + ds;
-                                                qx = __builtin_fma(dx, sl, bx), qy = __builtin_fma(dy, sl, by);
-                                                qz = __builtin_fma(dz, sl, bz);
+                                                qx = bx + dx * ds, qy = by + dy * ds, qz = bz + dz * ds;
                                                 /* a new line starts at q: B is at -ds on it */
                                                 if (f_sample_on_line<MODE>(v, ctx, qx, qy, qz, dx, dy,
                                                         dz, line, sl, s,
                                                         (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr))
-                                                        bx = qx, by = qy, bz = qz, line.s = -ds;
+                                                        line.s = -ds;
                                                 fail = (s.m != m) || (s.fault.centre >= 0);
                                         }
                                 }
@@ -1886,7 +1922,9 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                  * gets the same bits (line and cell now serve q) */
                                 if (__ballot(fail) != 0) break;
                                 if (ray >= 0) {
+                                        bx = qx, by = qy, bz = qz;
                                         line.s += ds;
+                                        line.tau += kLineDrift;
                                         len += ds;
                                         count++;
                                         k = s.k;
@@ -1977,6 +2015,11 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                          * cases are |alt - elevation| */
                                         double ds_next = clearance * v.slope;
                                         if (ds_next < v.resolution) ds_next = v.resolution;
+                                        /* B += d * ds, as the general iteration does it (a
+                                         * lane that is not going adds d * 0: B itself) */
+                                        const double moved = going ? ds : 0.;
+                                        bx = bx + dx * moved, by = by + dy * moved, bz = bz + dz * moved;
+                                        line.tau = going ? line.tau + kLineDrift : line.tau;
                                         line.s = going ? sl : line.s;
                                         len = going ? len + ds : len;
                                         count += going ? 1 : 0;
@@ -1992,9 +2035,9 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                  * to their 512th step with most lanes idle -- measured: the queue of
                  * C2 is dry after 2.4 ms and the last wave left at 4.5 ms.  Phase B
                  * packs them again, and has the time: it waits for its longest ray. */
-                const bool drain = !MODEL && (ph.park_after > 0) && exhausted && (ray >= 0) &&
+                const bool drain = !MODEL && (ph.parked != nullptr) && exhausted && (ray >= 0) &&
                     (state == ST_STEP) && (__popcll(__ballot(ray >= 0)) <= ph.drain_lanes);
-                bool park = drain;
+                bool park = drain, park_lined = false;
                 TileFault fault = { -1, 0, 0 }; /* the tiles to page in, if any */
                 double fx = 0, fy = 0, fz = 0; /* where the ray goes back to, then */
                 if ((ray >= 0) && !drain) {
@@ -2003,11 +2046,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         if (state == ST_STEP) t = ds;
                         if (state == ST_BISECT) t = 0.5 * (ds0 + ds1);
                         double qx = bx, qy = by, qz = bz;
-                        if (LINED && (state != ST_INIT)) {
-                                const double sl = line.s + t;
-                                qx = __builtin_fma(dx, sl, bx), qy = __builtin_fma(dy, sl, by);
-                                qz = __builtin_fma(dz, sl, bz);
-                        } else if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
+                        if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
                                 qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
 
                         Sample s;
@@ -2016,7 +2055,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                  * and a STEP sample then moves B to q */
                                 if (f_sample_on_line<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line,
                                         line.s + t, s, (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr))
-                                        bx = qx, by = qy, bz = qz, line.s = -t;
+                                        line.s = -t;
                                 if (state == ST_STEP) line.s += t;
                         } else
                                 d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
@@ -2029,14 +2068,8 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                  * not kept) and on the list for the next round */
                                 fault = s.fault;
                                 if (state == ST_INIT) home = -1; /* a new ray: nothing to keep */
-                                double back = (state == ST_BISECT) ? ds : 0.;
-                                if (LINED) {
-                                        back += (state == ST_STEP) ? t : 0.;
-                                        const double sb = line.s - back;
-                                        fx = __builtin_fma(dx, sb, bx), fy = __builtin_fma(dy, sb, by);
-                                        fz = __builtin_fma(dz, sb, bz);
-                                } else
-                                        fx = bx - dx * back, fy = by - dy * back, fz = bz - dz * back;
+                                const double back = (state == ST_BISECT) ? ds : 0.;
+                                fx = bx - dx * back, fy = by - dy * back, fz = bz - dz * back;
                         }
 
                         /* ---- bookkeeping ----
@@ -2077,9 +2110,8 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 const bool other = !same;              /* a sample of another medium */
                                 const double ds_next = d_step_length(v, s.alt, s.e0, s.e1, s.m);
                                 /* a STEP sample always moves B to q */
-                                if (!LINED)
-                                        bx = stepping ? qx : bx, by = stepping ? qy : by,
-                                        bz = stepping ? qz : bz;
+                                bx = stepping ? qx : bx, by = stepping ? qy : by, bz = stepping ? qz : bz;
+                                if (MODEL) line.tau = accept ? line.tau + kLineDrift : line.tau;
                                 len = accept ? len + ds : len;
                                 k = accept ? s.k : k;
                                 bm = other ? s.m : bm, bk = other ? s.k : bk;
@@ -2096,10 +2128,14 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 const bool capped = accept & (count >= max_steps);
                                 done = capped;
                                 my_capped += capped ? 1 : 0;
-                                /* on to the next phase (always at the same step count:
-                                 * the line a ray lays there is part of its arithmetic) */
-                                park = accept & !capped & (ph.park_after > 0) & (count >= ph.park_after);
-                                if (MODEL && accept && !capped && !park && !lined_ &&
+                                /* on to the last pass (always at the same step count: the
+                                 * line a ray lays there is part of its arithmetic), or
+                                 * to the next time slice */
+                                park_lined = !MODEL & accept & !capped & (ph.lined != nullptr) &
+                                    (count >= ph.line_after);
+                                park = !MODEL & accept & !capped & !park_lined & (ph.quantum > 0) &
+                                    (ph.parked != nullptr) & (count - count0 >= ph.quantum);
+                                if (MODEL && accept && !capped && !lined_ && (ph.line_after > 0) &&
                                     (count >= ph.line_after)) {
                                         /* phase B: from here on the ray steps on its line,
                                          * laid by a fresh sample of its position -- what a
@@ -2112,20 +2148,13 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                     (!(ds1 - ds0 > 1E-08) | (halvings > 1200));
                         }
                         if (located) { /* [ref stepper.c:861-863] */
-                                if (LINED)
-                                        line.s += ds1;
-                                else
-                                        bx = bx + dx * ds1, by = by + dy * ds1, bz = bz + dz * ds1;
+                                bx = bx + dx * ds1, by = by + dy * ds1, bz = bz + dz * ds1;
                                 len += ds + ds1;
                                 count++;
                                 m = bm, k = bk;
                                 done = true;
                         }
                         if (done) {
-                                if (LINED) {
-                                        bx = __builtin_fma(dx, line.s, bx), by = __builtin_fma(dy, line.s, by);
-                                        bz = __builtin_fma(dz, line.s, bz);
-                                }
                                 pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
                                 index[2 * ray] = m, index[2 * ray + 1] = k;
                                 if (length) length[ray] = len;
@@ -2135,28 +2164,32 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 ray = -1;
                         }
                 }
-                /* ---- park over-long rays (phase A; whole wave takes part) ---- */
-                const ull pmask = __ballot(park);
-                if (pmask != 0) {
-                        const int leader = __builtin_ctzll(pmask);
-                        ull base = 0;
-                        if ((int)(threadIdx.x & 63) == leader)
-                                base = atomicAdd(ph.n_parked, (ull)__popcll(pmask));
-                        base = __shfl(base, leader, 64);
-                        if (park) {
-                                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pmask >> 32),
-                                    __builtin_amdgcn_mbcnt_lo((unsigned)pmask, 0));
-                                ph.parked[base + rank] = (int)ray;
-                                if (LINED) {
-                                        bx = __builtin_fma(dx, line.s, bx), by = __builtin_fma(dy, line.s, by);
-                                        bz = __builtin_fma(dz, line.s, bz);
+                /* ---- hand rays over to a later pass (whole wave takes part) ---- */
+                if (!MODEL) {
+                        const ull pmask = __ballot(park), lmask = __ballot(park_lined);
+                        if ((pmask | lmask) != 0) {
+                                /* one atomic per list and wave */
+                                ull base = 0, lbase = 0;
+                                if ((threadIdx.x & 63) == 0) {
+                                        if (pmask != 0) base = atomicAdd(ph.n_parked, (ull)__popcll(pmask));
+                                        if (lmask != 0) lbase = atomicAdd(ph.n_lined, (ull)__popcll(lmask));
                                 }
-                                pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
-                                index[2 * ray] = m, index[2 * ray + 1] = k;
-                                length[ray] = len;
-                                n_steps[ray] = count;
-                                my_steps += (ull)(count - count0);
-                                ray = -1;
+                                base = __shfl(base, 0, 64), lbase = __shfl(lbase, 0, 64);
+                                if (park | park_lined) {
+                                        const ull mine = park ? pmask : lmask;
+                                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32),
+                                            __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
+                                        if (park)
+                                                ph.parked[base + rank] = (int)ray;
+                                        else
+                                                ph.lined[lbase + rank] = (int)ray;
+                                        pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
+                                        index[2 * ray] = m, index[2 * ray + 1] = k;
+                                        length[ray] = len;
+                                        n_steps[ray] = count;
+                                        my_steps += (ull)(count - count0);
+                                        ray = -1;
+                                }
                         }
                 }
                 /* ---- list the rays that wait for a tile (whole wave takes part) ---- */
@@ -2670,25 +2703,25 @@ static int env_int(const char * name, int fallback)
         return ((env != nullptr) && (*env != 0)) ? atoi(env) : fallback;
 }
 
-/* Step counts at which a ray moves on to the next phase of a fast trace (0: no
- * further phase), and the rays a wave of phase A may still hold when it hands
- * over after the queue ran dry.  TURTLE_AMD_* override them for experiments. */
+/* The step count from which a fast trace takes a ray on its line (0: never: one
+ * closed-form pass), the steps per time slice of the closed-form passes, and
+ * the rays a wave of such a pass may still hold when it hands over after its
+ * queue ran dry.  TURTLE_AMD_* override them for experiments. */
 static int park_threshold(void)
 {
         static int value = -1;
         if (value < 0) value = max(0, env_int("TURTLE_AMD_PARK", 512));
         return value;
 }
-static int park_threshold_2(void)
+static int slice_quantum(void)
 {
         static int value = -1;
-        if (value < 0) value = max(0, env_int("TURTLE_AMD_PARK2", 0));
+        if (value < 0) value = max(0, env_int("TURTLE_AMD_QUANTUM", 128));
         return value;
 }
 /* Few in a small batch, where the launch waits for single rays in all-but-empty
- * waves (C2, 1 M rays: 8 lanes 6.85 ms, 32 lanes 7.08, 64 lanes 7.4); more in a large
- * one, where phase B is a matter of throughput (C2 at 4 M rays: 20.5 -> 19.6 ms with 32;
- * C3, 10 M: 42.6 -> 41.8).  The loop gives the same bits whenever it engages. */
+ * waves; more in a large one, where the last pass is a matter of throughput.  The
+ * loop gives the same bits whenever it engages. */
 static int creep_lanes(long n)
 {
         static int value = -2;
@@ -2706,16 +2739,18 @@ static int drain_lanes(void)
 /* One round of a trace: all the rays (pg.ids == NULL), or the ones the last
  * round listed because they needed a tile (they carry on from the arrays).
  *
- * Fast arithmetic runs in phases, each with fewer and longer rays than the one
- * before: A steps everything to 512 steps and hands over what is left when its
- * queue runs dry (C2: 260 k of 1 M rays); B takes those to the end.  A ray
- * changes phase at fixed step counts, or (below 512 steps) where its arithmetic
- * does not depend on the phase: see LINED.  A third phase C for the rays beyond
- * a second threshold (TURTLE_AMD_PARK2; a few to a wave, on an otherwise empty
- * chip) is wired in but off: measured on C2, every threshold from 544 to 2 048
- * made the trace slower (8.5-9.5 ms against 7.5 ms) -- what phase B waits for
- * is not its one longest ray but the medium ones (1 000-2 500 steps) stepping in
- * waves that are neither full nor down to a handful of rays. */
+ * Fast arithmetic runs in passes (see PhaseIO): closed-form passes in time
+ * slices of `quantum` steps, each taking the list the one before wrote -- as many
+ * as a ray needs to reach `park` steps, then two more for what the others hand
+ * over when their queues run dry (the last one never hands over) -- and the
+ * lined pass for the rays that got that far.  A pass whose list is empty costs a
+ * launch of idle blocks (~5 us).  Batches that fit the chip's lanes a couple of
+ * times over are not sliced: every ray starts at once anyway.
+ *
+ * parked: room for 3 n ray ids (two lists the closed-form passes alternate
+ * between, and the lined list); queue: TAMD_TRACE_COUNTERS words, zeroed:
+ * [k] the work queue of pass k, [12 + k] the length of the list pass k wrote,
+ * [11] the length of the lined list. */
 template <int MODE>
 static int run_trace(struct tamd_view view, long n, double * pos, const double * dir,
     int max_steps, int * index, double * length, int * n_steps, int flags, int * parked,
@@ -2724,7 +2759,8 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         const bool again = (pg.ids != nullptr);
         if (again) flags |= TRACE_CARRY_MEDIUM;
         const int resume = again ? 2 : 0;
-        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, resume, pg, 0, 0, kChunk, creep_lanes(n) };
+        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, nullptr, nullptr, 0, resume, pg, 0, 0,
+                kChunk, creep_lanes(n) };
         if (g_math_strict || !view.fast_ok)
                 return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
@@ -2733,28 +2769,35 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
             (n_steps == nullptr))
                 return launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
-        /* lists: parked[0 .. n) from A to B, parked[n .. 2n) from B to C; counters:
-         * queue[0], [1], [3]: the work queues of A, B, C; queue[2], [4]: the lists */
-        int park2 = park_threshold_2();
-        if ((park2 <= park) || (max_steps <= park2)) park2 = 0;
-        const PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, resume, pg, drain_lanes(), 0,
-                kChunk, creep_lanes(n) };
-        if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
-                n_steps, flags, a, stats, queue))
+        int * const list[2] = { parked, parked + n };
+        int * const lined = parked + 2 * n;
+        ull * const n_lined = queue + 11;
+        const long in_flight = (long)g_cus * 4 * 4 * 64; /* lanes of a closed-form pass */
+        int quantum = slice_quantum();
+        if ((n <= 2 * in_flight) || (quantum >= park)) quantum = 0;
+        const int sliced = (quantum > 0) ? (park + quantum - 1) / quantum : 1;
+        const int passes = sliced + 2;
+        if (passes > 10) {
+                snprintf(g_error, sizeof(g_error), "TURTLE_AMD_QUANTUM is too small for TURTLE_AMD_PARK");
                 return 1;
-        const PhaseIO b = { parked, queue + 2, park2 ? parked + n : nullptr, queue + 4, park2, 1, pg,
-                0, park, kChunk, creep_lanes(n) };
-        if (launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
-                n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1))
-                return 1;
-        if (park2 == 0) return 0;
-        const PhaseIO c = { parked + n, queue + 4, nullptr, nullptr, 0, 1, pg, 0, park, kTailChunk, creep_lanes(n) };
+        }
+        for (int k = 0; k < passes; k++) {
+                const bool last = (k == passes - 1);
+                PhaseIO a = { pg.ids, pg.n_in, last ? nullptr : list[k & 1], queue + 12 + k, lined, n_lined,
+                        (k < sliced) ? quantum : 0, resume, pg, drain_lanes(), park, kChunk, creep_lanes(n) };
+                if (k > 0) a.ids = list[(k - 1) & 1], a.n_dev = queue + 12 + k - 1, a.accumulate = 1;
+                if (launch_trace<MODE, true, false>(view, n, again || (k > 0), pos, dir, max_steps, index,
+                        length, n_steps, (k > 0) ? (flags | TRACE_CARRY_MEDIUM) : flags, a, stats, queue + k))
+                        return 1;
+        }
+        const PhaseIO b = { lined, n_lined, nullptr, nullptr, nullptr, nullptr, 0, 1, pg, 0, park, kChunk,
+                creep_lanes(n) };
         return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
-            n_steps, flags | TRACE_CARRY_MEDIUM, c, stats, queue + 3);
+            n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 10);
 }
 
-/* queue: five counters (see run_trace); parked: room for 2 n ray ids.  pg: the round of a paged geometry (paging.c), all NULL otherwise; the
- * counters in `stats` add up over the rounds of a call. */
+/* parked, queue: see run_trace.  pg: the round of a paged geometry (paging.c), all
+ * NULL otherwise; the counters in `stats` add up over the rounds of a call. */
 extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
     int flags, int * parked, struct tamd_paging pg, unsigned long long * stats,
@@ -2762,7 +2805,7 @@ extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
 {
         if (tamd_dev_init()) return 1;
         if (pg.ids == nullptr) HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
-        HIP_TRY(hipMemsetAsync(queue, 0, 5 * sizeof(ull), g_stream));
+        HIP_TRY(hipMemsetAsync(queue, 0, TAMD_TRACE_COUNTERS * sizeof(ull), g_stream));
         if (n <= 0) return 0;
         const int carry = (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0;
         if (view.mode == TAMD_MODE_ONE_MAP)

@@ -152,7 +152,7 @@ struct turtle_stepper {
         size_t d_tables_size;
         struct tamd_view view;
         int n_table;                  /* entries of the tile table (all stacks) */
-        unsigned long long * d_stats; /* 16 words: 4 stats + the counters of a trace */
+        unsigned long long * d_stats; /* 4 stats + the TAMD_TRACE_COUNTERS of a trace */
         int * d_parked;               /* scratch of the batch calls: ray ids ... */
         double * d_scratch_ds;        /* ... and one double each (same block) */
         long parked_capacity;

@@ -182,10 +182,12 @@ int tamd_k_position(struct tamd_view view, long n, const double * lat,
 int tamd_k_step(struct tamd_view view, long n, double * pos,
     const double * dir, double * lat, double * lon, double * alt,
     double * elev, double * step, int * index, int flags, struct tamd_paging pg);
-/* stats: 4 x uint64 on the device (rays, steps, samples, capped); queue: 3 x
- * uint64 (work counters of the two phases, number of parked rays); both zeroed
- * by the launcher.  parked: int[n] scratch for the ids of rays handed to the
- * second phase, or NULL for a single-phase launch. */
+/* stats: 4 x uint64 on the device (rays, steps, samples, capped); queue:
+ * TAMD_TRACE_COUNTERS x uint64 (work queues and list lengths of the passes of a
+ * fast trace: see run_trace in device.hip); both zeroed by the launcher.
+ * parked: int[3 n] scratch for the lists of rays handed from pass to pass, or
+ * NULL for a single-pass launch. */
+#define TAMD_TRACE_COUNTERS 24
 int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length,
     int * n_steps, int flags, int * parked, struct tamd_paging pg,

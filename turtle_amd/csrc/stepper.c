@@ -241,8 +241,9 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
 {
         if (tamd_dev_init()) return -1;
         if (s->d_stats == NULL) {
-                if (tamd_dev_malloc((void **)&s->d_stats, 16 * sizeof(*s->d_stats))) return -1;
-                if (tamd_dev_zero(s->d_stats, 16 * sizeof(*s->d_stats))) return -1;
+                const size_t words = 4 + TAMD_TRACE_COUNTERS;
+                if (tamd_dev_malloc((void **)&s->d_stats, words * sizeof(*s->d_stats))) return -1;
+                if (tamd_dev_zero(s->d_stats, words * sizeof(*s->d_stats))) return -1;
         }
         s->view.slope = s->slope_factor;
         s->view.resolution = s->resolution_factor;
@@ -537,8 +538,8 @@ enum turtle_return turtle_stepper_position_n(struct turtle_stepper * stepper, lo
         return TURTLE_RETURN_SUCCESS;
 }
 
-/* Grow-only scratch of the batch calls: 2 n ints (the rays a trace hands from
- * phase to phase / the rays a batch of steps defers to its bisection pass)
+/* Grow-only scratch of the batch calls: 3 n ints (the rays a trace hands from
+ * pass to pass / the rays a batch of steps defers to its bisection pass)
  * followed by n doubles.  0 if it holds n entries; 1 if n is beyond an int
  * (the caller does without); parked_capacity < 0 after a device failure. */
 static int tamd_stepper_scratch(struct turtle_stepper * stepper, long n)
@@ -550,7 +551,7 @@ static int tamd_stepper_scratch(struct turtle_stepper * stepper, long n)
                 tamd_dev_free(stepper->d_parked);
                 stepper->d_parked = NULL;
         }
-        const size_t ints = (((size_t)n * 2 * sizeof(int) + 255) / 256) * 256; /* two lists */
+        const size_t ints = (((size_t)n * 3 * sizeof(int) + 255) / 256) * 256; /* three lists */
         stepper->parked_capacity = 0;
         if (tamd_dev_malloc((void **)&stepper->d_parked, ints + (size_t)n * sizeof(double))) {
                 stepper->parked_capacity = -1;
