@@ -105,24 +105,26 @@ def test_c2_properties(c2):
 
 
 def test_creep_loop_changes_no_bit(tmp_path):
-    """The lean loops of phase B take the samples the general
+    """The lean forms of the lined pass take the samples the general
     iteration would take, with the same functions on the same values: a batch with
-    thousands-of-steps rays gives the same bits with the loops off
-    (TURTLE_AMD_CREEP_LANES=0), at their default, and engaging at any number of
-    live lanes (64) -- through one map and through a regular stack."""
+    thousands-of-steps rays gives the same bits with the creep loops off
+    (TURTLE_AMD_CREEP_LANES=0), at their default, engaging at any number of live
+    lanes (64), and with the lean sampling of the general iteration off
+    (TURTLE_AMD_LEAN=0: every sample through f_sample_on_line) -- through one map
+    and through a regular stack."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     results = {}
-    for lanes in ("0", "8", "64"):
-        out = os.path.join(tmp_path, f"lanes{lanes}.npz")
-        work = os.path.join(tmp_path, f"work{lanes}")
-        env = dict(os.environ, TURTLE_AMD_CREEP_LANES=lanes)
+    for lanes, lean in (("0", "0"), ("0", "1"), ("8", "1"), ("64", "1"), ("8", "0")):
+        out = os.path.join(tmp_path, f"lanes{lanes}_{lean}.npz")
+        work = os.path.join(tmp_path, f"work{lanes}_{lean}")
+        env = dict(os.environ, TURTLE_AMD_CREEP_LANES=lanes, TURTLE_AMD_LEAN=lean)
         subprocess.run([sys.executable, os.path.join(here, "creep_probe.py"), out, work],
                        check=True, env=env, timeout=300)
-        results[lanes] = dict(np.load(out))
-    base = results["0"]
+        results[(lanes, lean)] = dict(np.load(out))
+    base = results[("0", "0")]
     assert base["map_n_steps"].max() > 2000 and base["stack_n_steps"].max() > 2000
-    for lanes in ("8", "64"):
+    for which, r in results.items():
         for key, ref in base.items():
-            assert np.array_equal(results[lanes][key], ref), (lanes, key)
+            assert np.array_equal(r[key], ref), (which, key)

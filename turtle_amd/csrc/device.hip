@@ -1795,6 +1795,8 @@ struct PhaseIO {
                               * LINED); <= 0: never (single-pass launches) */
         int chunk;           /* rays a wave draws from the queue at once */
         int creep_lanes;     /* the creep loop engages at or below this many live lanes */
+        int lean;            /* lined pass: samples served by the line and the cached cell take the
+                              * lean way (see LEAN in k_trace); 0: all through f_sample_on_line */
 };
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
@@ -1824,6 +1826,28 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         OneCtx ctx;
         d_load_ctx<MODE, FAST>(v, ctx);
         CellCache cell = { ~0u, 0u, 0u, -1, nullptr };
+        /* LEAN (the lined pass over one map or one regular stack): the cached cell
+         * DECODED -- its node coordinates as doubles, its four elevations, the origin
+         * of its tile -- so that a sample the line serves inside that cell needs no
+         * load, no conversion between integers and doubles (a quarter of the rate of
+         * the other instructions) and none of the general lookup's cases; and a cell
+         * the lane has asked for and not yet received (`pending`: the loads fly
+         * while the other lanes take their samples; the lane takes its own one trip
+         * later).  Same values as f_grid_locate / f_grid_blend / f_stack_elevation
+         * produce: for an interior point (double)(int)hx == trunc(hx), and the clamp
+         * of the cell index does nothing. */
+        constexpr bool LEAN = MODEL && (MODE != TAMD_MODE_GENERIC);
+        constexpr bool LEAN_STACK = (MODE == TAMD_MODE_ONE_STACK);
+        const bool lean_ok = LEAN && (ph.lean != 0) && (!LEAN_STACK || (ctx.stack.regular != 0));
+        const tamd_grid & lg = LEAN_STACK ? ctx.stack.proto : ctx.grid;
+        constexpr double lean_guard = LEAN_STACK ? kSeamGuard : 1e-6;
+        const double lean_mx = (double)(lg.nx - 1) - lean_guard, lean_my = (double)(lg.ny - 1) - lean_guard;
+        unsigned dec_id = ~0u; /* the cell.id the decoded values stand for */
+        double dec_cx = -1., dec_cy = -1., dec_x0 = 0., dec_y0 = 0.;
+        double z00 = 0., z10 = 0., z01 = 0., z11 = 0.;
+        bool pending = false;
+        unsigned pend_lo = 0, pend_hi = 0;
+        int pend_ix = 0, pend_iy = 0;
 
         long ray = -1;
         bool dead = false;
@@ -1897,8 +1921,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                  * having committed that step.  It calls the same functions on
                  * the same values as the general path, so results do not depend
                  * on whether it engaged. */
-                if (MODEL && (MODE != TAMD_MODE_ONE_MAP) &&
-                    !((MODE == TAMD_MODE_ONE_STACK) && ctx.stack.regular) && /* -> the lean loop below */
+                if (MODEL && !(LEAN && lean_ok) && /* -> the lean loop below */
                     (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
                         for (int it = 0; it < 4096; it++) {
                                 bool fail = false;
@@ -1934,60 +1957,67 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         }
                 }
 
-                /* The single-map case gets a leaner body still: only the line and
-                 * the cached cell (no closed form, no fetch inside; a lane that
-                 * needs either leaves for one general iteration).  What a launch
-                 * waits for in the end is ONE ray -- C2's longest takes 11 326 steps,
-                 * most of them here, alone in its wave -- so what counts is the
-                 * latency of a trip, and a good part of that is the wave-wide
-                 * question "does any lane have to leave?" (compare, ballot, branch:
-                 * the vector and scalar units wait for each other).  It is asked once
-                 * per kCreepUnroll steps: a lane that cannot take one of them takes
-                 * none of the following either (nothing is committed from there on),
-                 * and the wave leaves after the group. */
-                if (MODEL &&
-                    ((MODE == TAMD_MODE_ONE_MAP) || ((MODE == TAMD_MODE_ONE_STACK) && ctx.stack.regular)) &&
-                    (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
-                        /* one map: the grid.  A regular stack: the tile the cached cell is
-                         * in -- the shared tile shape at that tile's origin, computed as
-                         * f_stack_elevation computes it; a point `interior` to it (same
-                         * guard as there) gets that tile from the directory too */
-                        constexpr bool STACK = (MODE == TAMD_MODE_ONE_STACK);
-                        const tamd_grid & g = STACK ? ctx.stack.proto : ctx.grid;
-                        constexpr double guard = STACK ? kSeamGuard : 1e-6;
-                        const double mx = (double)(g.nx - 1) - guard, my = (double)(g.ny - 1) - guard;
-                        const bool cached = (cell.id != ~0u);
-                        const unsigned slot = STACK ? (cell.id >> 24) : 0u;
-                        const unsigned cell_index = STACK ? (cell.id & 0xffffffu) : cell.id;
-                        const unsigned tile_y = STACK ? slot / (unsigned)ctx.stack.nlon : 0u;
-                        const unsigned tile_x = STACK ? slot - tile_y * (unsigned)ctx.stack.nlon : 0u;
-                        const double x0 = STACK ? ctx.stack.lon0 + (int)tile_x * ctx.stack.dlon : g.x0;
-                        const double y0 = STACK ? ctx.stack.lat0 + (int)tile_y * ctx.stack.dlat : g.y0;
-                        /* The cached cell, decoded once per entry: its node coordinates
-                         * as doubles and its four elevations -- a trip then needs no
-                         * conversion between integers and doubles (a quarter of the
-                         * rate of the other instructions, and on the chain).  Same
-                         * values as f_grid_locate / f_grid_blend produce: for an
-                         * interior point (double)(int)hx == trunc(hx), and the clamp of
-                         * the cell index does nothing. */
-                        const unsigned cell_iy = cached ? cell_index / (unsigned)g.nx : 0u;
-                        const double cy = cached ? (double)cell_iy : -1.;
-                        const double cx = cached ? (double)(cell_index - cell_iy * (unsigned)g.nx) : -1.;
-                        double z00, z10, z01, z11;
-                        if (g.is_signed) {
-                                z00 = (double)(int16_t)(cell.lo & 0xffffu), z10 = (double)((int)cell.lo >> 16);
-                                z01 = (double)(int16_t)(cell.hi & 0xffffu), z11 = (double)((int)cell.hi >> 16);
-                        } else {
-                                z00 = (double)(cell.lo & 0xffffu), z10 = (double)(cell.lo >> 16);
-                                z01 = (double)(cell.hi & 0xffffu), z11 = (double)(cell.hi >> 16);
+                /* ---- LEAN: the decoded cell follows the cached one ---- */
+                if (LEAN && lean_ok) {
+                        const bool arrived = pending, moved = !pending & (cell.id != dec_id);
+                        if (__ballot(arrived | moved) != 0) {
+                                if (arrived) { /* the cell asked for on the last trip (same tile) */
+                                        const unsigned slot = LEAN_STACK ? (cell.id >> 24) : 0u;
+                                        cell.id = (slot << 24) | ((unsigned)pend_iy * (unsigned)lg.nx + (unsigned)pend_ix);
+                                        cell.lo = pend_lo, cell.hi = pend_hi;
+                                        dec_cx = (double)pend_ix, dec_cy = (double)pend_iy;
+                                        pending = false;
+                                }
+                                if (moved) { /* the general lookup moved the cache */
+                                        const bool cached = (cell.id != ~0u);
+                                        const unsigned slot = LEAN_STACK ? (cell.id >> 24) : 0u;
+                                        const unsigned cell_index = LEAN_STACK ? (cell.id & 0xffffffu) : cell.id;
+                                        const unsigned tile_y = LEAN_STACK ? slot / (unsigned)ctx.stack.nlon : 0u;
+                                        const unsigned tile_x = LEAN_STACK ? slot - tile_y * (unsigned)ctx.stack.nlon : 0u;
+                                        /* the tile's origin as f_stack_elevation computes it */
+                                        dec_x0 = LEAN_STACK ? ctx.stack.lon0 + (int)tile_x * ctx.stack.dlon : lg.x0;
+                                        dec_y0 = LEAN_STACK ? ctx.stack.lat0 + (int)tile_y * ctx.stack.dlat : lg.y0;
+                                        const unsigned cell_iy = cached ? cell_index / (unsigned)lg.nx : 0u;
+                                        dec_cy = cached ? (double)cell_iy : -1.;
+                                        dec_cx = cached ? (double)(cell_index - cell_iy * (unsigned)lg.nx) : -1.;
+                                }
+                                if (arrived | moved) {
+                                        dec_id = cell.id;
+                                        if (lg.is_signed) {
+                                                z00 = (double)(int16_t)(cell.lo & 0xffffu), z10 = (double)((int)cell.lo >> 16);
+                                                z01 = (double)(int16_t)(cell.hi & 0xffffu), z11 = (double)((int)cell.hi >> 16);
+                                        } else {
+                                                z00 = (double)(cell.lo & 0xffffu), z10 = (double)(cell.lo >> 16);
+                                                z01 = (double)(cell.hi & 0xffffu), z11 = (double)(cell.hi >> 16);
+                                        }
+                                        z00 = __builtin_fma(z00, lg.dz, lg.z0), z10 = __builtin_fma(z10, lg.dz, lg.z0);
+                                        z01 = __builtin_fma(z01, lg.dz, lg.z0), z11 = __builtin_fma(z11, lg.dz, lg.z0);
+                                }
                         }
-                        z00 = __builtin_fma(z00, g.dz, g.z0), z10 = __builtin_fma(z10, g.dz, g.z0);
-                        z01 = __builtin_fma(z01, g.dz, g.z0), z11 = __builtin_fma(z11, g.dz, g.z0);
+                }
+
+                /* ---- creep loop, lean form ---------------------------------------
+                 * When a wave is down to a few rays, all stepping on their lines inside
+                 * their decoded cells, a step needs no state machine either.  What a
+                 * launch waits for in the end is ONE ray -- C2's longest takes 11 326
+                 * steps, most of them here, alone in its wave -- so what counts is the
+                 * latency of a trip, and a good part of that is the wave-wide question
+                 * "does any lane have to leave?" (compare, ballot, branch: the vector
+                 * and scalar units wait for each other).  It is asked once per
+                 * kCreepUnroll steps: a lane that cannot take one of them takes none of
+                 * the following either (nothing is committed from there on), and the
+                 * wave leaves after the group.  Same functions on the same values as
+                 * the general iteration: results do not depend on whether it engaged. */
+                if (LEAN && lean_ok && (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
+                        const tamd_grid & g = lg;
+                        constexpr double guard = lean_guard;
+                        const double mx = lean_mx, my = lean_my;
+                        const double x0 = dec_x0, y0 = dec_y0, cx = dec_cx, cy = dec_cy;
                         for (int it = 0; it < 4096; it++) {
                                 /* no short-circuits below: every lane computes
                                  * everything (garbage is harmless, nothing is
                                  * committed on failure) and the tests are AND-ed */
-                                bool going = (ray >= 0) & (state == ST_STEP) & lined_ & line.valid;
+                                bool going = (ray >= 0) & (state == ST_STEP) & lined_ & line.valid & !pending;
 #pragma unroll
                                 for (int u = 0; u < kCreepUnroll; u++) {
                                         const double sl = line.s + ds;
@@ -2040,26 +2070,74 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                 bool park = drain, park_lined = false;
                 TileFault fault = { -1, 0, 0 }; /* the tiles to page in, if any */
                 double fx = 0, fy = 0, fz = 0; /* where the ray goes back to, then */
-                if ((ray >= 0) && !drain) {
-                        /* ---- one sample at q = B + d * t ---- */
-                        double t = 0.;
-                        if (state == ST_STEP) t = ds;
-                        if (state == ST_BISECT) t = 0.5 * (ds0 + ds1);
-                        double qx = bx, qy = by, qz = bz;
-                        if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
-                                qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
-
-                        Sample s;
-                        if (LINED) {
-                                /* B's parameter: -t on a new line (its origin is q),
-                                 * and a STEP sample then moves B to q */
-                                if (f_sample_on_line<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line,
-                                        line.s + t, s, (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr))
-                                        line.s = -t;
+                /* ---- one sample at q = B + d * t ---- */
+                double t = 0.;
+                if (state == ST_STEP) t = ds;
+                if (state == ST_BISECT) t = 0.5 * (ds0 + ds1);
+                Sample s;
+                bool sampled = false; /* LEAN: the sample is in `s` already */
+                bool waits = false;   /* LEAN: the lane has asked for its cell: no sample on this trip */
+                if (LEAN && lean_ok) {
+                        /* every lane computes everything (garbage is harmless: the
+                         * flags decide what is used), as in the creep loop */
+                        const bool can = (ray >= 0) & lined_ & line.valid & (state != ST_INIT);
+                        const double sl = line.s + t;
+                        double lat, lon, alt;
+                        f_line_eval(line, sl, lat, lon, alt);
+                        const double hx = (lon - dec_x0) * lg.inv_dx;
+                        const double hy = (lat - dec_y0) * lg.inv_dy;
+                        const bool interior =
+                            (hx > lean_guard) & (hx < lean_mx) & (hy > lean_guard) & (hy < lean_my);
+                        const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);
+                        const double fx_ = hx - tx, fy_ = hy - ty;
+                        const double gx = 1. - fx_, gy = 1. - fy_;
+                        const double elevation =
+                            (z00 * gx * gy + z01 * gx * fy_ + z10 * fx_ * gy + z11 * fx_ * fy_) + ctx.offset;
+                        const double clearance = fabs(alt - elevation);
+                        const bool here = can & (fabs(sl) <= kLineRange) & interior & (dec_cx >= 0.);
+                        const bool incell = (tx == dec_cx) & (ty == dec_cy);
+                        sampled = here & incell & f_line_serves(line, sl, clearance);
+                        /* another cell of the same tile: ask for its nodes, and take the
+                         * sample on the next trip (the wave does not wait for them now) */
+                        waits = here & !incell;
+                        if (__ballot(waits) != 0) {
+                                if (waits) {
+                                        const unsigned slot = LEAN_STACK ? (cell.id >> 24) : 0u;
+                                        const uint16_t * nodes = LEAN_STACK ? ctx.slots[slot] : lg.nodes;
+                                        pend_ix = (int)tx, pend_iy = (int)ty;
+                                        d_cell_fetch(nodes, lg.nbx, pend_ix, pend_iy, pend_lo, pend_hi);
+                                        pending = true;
+                                }
+                        }
+                        if (sampled) {
+                                s.lat = lat, s.lon = lon, s.alt = alt;
+                                s.fault.centre = -1, s.slot = -1, s.k = 0;
+                                const bool below = (elevation >= alt); /* as d_classify */
+                                s.m = below ? 0 : 1;
+                                s.e0 = below ? -DBL_MAX : elevation;
+                                s.e1 = below ? elevation : DBL_MAX;
                                 if (state == ST_STEP) line.s += t;
-                        } else
-                                d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
-                                    (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr);
+                        }
+                }
+                const bool slow = (ray >= 0) & !drain & !sampled & !waits;
+                double qx = bx, qy = by, qz = bz;
+                if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
+                        qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
+                if (__ballot(slow) != 0) {
+                        if (slow) {
+                                if (LINED) {
+                                        /* B's parameter: -t on a new line (its origin is q),
+                                         * and a STEP sample then moves B to q */
+                                        if (f_sample_on_line<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line,
+                                                line.s + t, s, (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr))
+                                                line.s = -t;
+                                        if (state == ST_STEP) line.s += t;
+                                } else
+                                        d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
+                                            (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr);
+                        }
+                }
+                if ((ray >= 0) && !drain && (sampled | slow)) {
                         my_samples++;
                         if (CAN_FAULT && (s.fault.centre >= 0)) {
                                 /* a tile that is not resident: the ray goes back to
@@ -2135,15 +2213,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                     (count >= ph.line_after);
                                 park = !MODEL & accept & !capped & !park_lined & (ph.quantum > 0) &
                                     (ph.parked != nullptr) & (count - count0 >= ph.quantum);
-                                if (MODEL && accept && !capped && !lined_ && (ph.line_after > 0) &&
-                                    (count >= ph.line_after)) {
-                                        /* phase B: from here on the ray steps on its line,
-                                         * laid by a fresh sample of its position -- what a
-                                         * ray handed over at this very step goes through */
-                                        lined_ = true;
-                                        line.valid = false, line.s = 0.;
-                                        state = ST_INIT;
-                                }
                                 located = (state == ST_BISECT) &
                                     (!(ds1 - ds0 > 1E-08) | (halvings > 1200));
                         }
@@ -2739,13 +2808,9 @@ static int drain_lanes(void)
 /* One round of a trace: all the rays (pg.ids == NULL), or the ones the last
  * round listed because they needed a tile (they carry on from the arrays).
  *
- * Fast arithmetic runs in passes (see PhaseIO): closed-form passes in time
- * slices of `quantum` steps, each taking the list the one before wrote -- as many
- * as a ray needs to reach `park` steps, then two more for what the others hand
- * over when their queues run dry (the last one never hands over) -- and the
- * lined pass for the rays that got that far.  A pass whose list is empty costs a
- * launch of idle blocks (~5 us).  Batches that fit the chip's lanes a couple of
- * times over are not sliced: every ray starts at once anyway.
+ * Fast arithmetic runs in passes (see PhaseIO): closed-form passes, each taking
+ * the list the one before wrote, and the lined pass for the rays that reached
+ * `park` steps.  A pass whose list is empty costs a launch of idle blocks (~5 us).
  *
  * parked: room for 3 n ray ids (two lists the closed-form passes alternate
  * between, and the lined list); queue: TAMD_TRACE_COUNTERS words, zeroed:
@@ -2760,7 +2825,7 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         if (again) flags |= TRACE_CARRY_MEDIUM;
         const int resume = again ? 2 : 0;
         const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, nullptr, nullptr, 0, resume, pg, 0, 0,
-                kChunk, creep_lanes(n) };
+                kChunk, creep_lanes(n), 0 };
         if (g_math_strict || !view.fast_ok)
                 return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
@@ -2772,26 +2837,29 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         int * const list[2] = { parked, parked + n };
         int * const lined = parked + 2 * n;
         ull * const n_lined = queue + 11;
-        const long in_flight = (long)g_cus * 4 * 4 * 64; /* lanes of a closed-form pass */
-        int quantum = slice_quantum();
-        if ((n <= 2 * in_flight) || (quantum >= park)) quantum = 0;
-        const int sliced = (quantum > 0) ? (park + quantum - 1) / quantum : 1;
-        const int passes = sliced + 2;
-        if (passes > 10) {
+        /* pass 0: everything, up to `park` steps, handing over what it holds when its
+         * queue runs dry; then the TAIL passes over what was handed over (at most one
+         * ray per lane of the chip, all of them starting at once: nothing to refill
+         * with, so their waves thin out as rays end): in slices of `quantum` steps,
+         * each packing the survivors of the one before into full waves again */
+        const int quantum = (slice_quantum() < park) ? slice_quantum() : 0;
+        const int tails = (quantum > 0) ? (park + quantum - 1) / quantum : 1;
+        if (tails > 9) {
                 snprintf(g_error, sizeof(g_error), "TURTLE_AMD_QUANTUM is too small for TURTLE_AMD_PARK");
                 return 1;
         }
-        for (int k = 0; k < passes; k++) {
-                const bool last = (k == passes - 1);
+        for (int k = 0; k <= tails; k++) {
+                const bool last = (k == tails);
                 PhaseIO a = { pg.ids, pg.n_in, last ? nullptr : list[k & 1], queue + 12 + k, lined, n_lined,
-                        (k < sliced) ? quantum : 0, resume, pg, drain_lanes(), park, kChunk, creep_lanes(n) };
+                        ((k > 0) && !last) ? quantum : 0, resume, pg, (k == 0) ? drain_lanes() : 0, park,
+                        kChunk, creep_lanes(n), 0 };
                 if (k > 0) a.ids = list[(k - 1) & 1], a.n_dev = queue + 12 + k - 1, a.accumulate = 1;
                 if (launch_trace<MODE, true, false>(view, n, again || (k > 0), pos, dir, max_steps, index,
                         length, n_steps, (k > 0) ? (flags | TRACE_CARRY_MEDIUM) : flags, a, stats, queue + k))
                         return 1;
         }
         const PhaseIO b = { lined, n_lined, nullptr, nullptr, nullptr, nullptr, 0, 1, pg, 0, park, kChunk,
-                creep_lanes(n) };
+                creep_lanes(n), env_int("TURTLE_AMD_LEAN", 1) };
         return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
             n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 10);
 }
