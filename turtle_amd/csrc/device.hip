@@ -267,13 +267,16 @@ constexpr double kLineTolerance = 2e-10; /* see f_line_accurate */
  * O + d * s, which is off the reference's by that drift.  That is harmless where
  * it only sizes the next step, and decisive where the medium is decided within
  * the drift of the boundary (a ray tangent to the ground: one step more or
- * less is 1e-2 m of path).  So the line keeps count of what its origin's
- * closed form, its truncation and the drift since it was laid can amount to
- * (tau: kLineTau0 at the origin + kLineDrift per accepted step), and a sample
- * whose clearance is not above it is taken again by the closed form AT THE
- * ACCUMULATED POSITION, as phase A would: every medium decision is then the
- * closed form's, to well below its own noise. */
-constexpr double kLineTau0 = 1e-8;  /* m: 3 x the closed form's own bound (3e-9 m) */
+ * less is 1e-2 m of path).  So the line keeps count of what its truncation and
+ * the drift since it was laid can amount to (tau: kLineTau0 at the origin +
+ * kLineDrift per accepted step), and a sample whose clearance is not above it is
+ * taken again by the closed form AT THE ACCUMULATED POSITION, as the closed-form
+ * passes would -- which lays a new line there, whose drift starts from nothing
+ * (the samples of a bisection all leave from one accumulated position: the line
+ * laid at the first of them that is too close to call serves the others). */
+constexpr double kLineTau0 = 1e-9;  /* m: the truncation allowed near a boundary (2e-10 m) and
+                                     * the rounding of latitude and longitude (8e-10 m on the
+                                     * ground, a third of that in elevation) */
 constexpr double kLineDrift = 1e-9; /* m per step: (3 x (2^-31)^2)^0.5 = 8.1e-10 rounded up */
 
 struct RayLine {
@@ -385,7 +388,7 @@ __device__ __forceinline__ void f_line_build(RayLine & L, double latitude, doubl
 
 __device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
     double & latitude, double & longitude, double & altitude, RayLine * build = nullptr,
-    double dx = 0., double dy = 0., double dz = 0., bool lay = true /* build: only if */)
+    double dx = 0., double dy = 0., double dz = 0.)
 {
         constexpr double kRad2Deg = 57.29577951308232;
         const double a = kA;
@@ -401,7 +404,7 @@ __device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
                 latitude = (z >= 0.) ? 90. : -90.;
                 longitude = 0.;
                 altitude = fabs(z) - kB;
-                if ((build != nullptr) && lay) build->valid = false;
+                if (build != nullptr) build->valid = false;
                 return;
         }
 
@@ -451,7 +454,7 @@ __device__ __forceinline__ void f_to_geodetic(double x, double y, double z,
         latitude = la * kRad2Deg;
         altitude = __builtin_fma(0.5 * m, p, f);
 
-        if ((build != nullptr) && lay) { /* everything it needs is at hand */
+        if (build != nullptr) { /* everything it needs is at hand */
                 /* sine and cosine of the corrected latitude, and the radii there:
                  * p is ~4e-8 rad, which the radii of the seed would turn into
                  * 4e-10 of the distance along the line (2e-7 m at 500 m) */
@@ -1152,30 +1155,26 @@ __device__ __forceinline__ void d_sample(const tamd_view & v, const OneCtx & ctx
 
 /* A sample of a ray that carries a line: at (x, y, z) -- the ray's accumulated
  * position, moved by the tentative length -- which is parameter sl of the line.
- * Taken from the line if it serves.  Else by the closed form at (x, y, z): if the
- * line is out of its range or of its accuracy there, that lays a new line
- * through the point (origin there: the caller re-bases its path parameter) and
- * true is returned; if the line is fine but the sample came out within its drift
- * of a boundary (f_line_serves) the line stays.  Which of these happens
+ * Taken from the line if it serves (f_line_serves); else by the closed form at
+ * (x, y, z), which lays a new line through the point (origin there: the caller
+ * re-bases its path parameter), and true is returned.  Which of the two happens
  * depends on the ray's own line, position and sample only. */
 template <int MODE>
 __device__ __forceinline__ bool f_sample_on_line(const tamd_view & v, const OneCtx & ctx,
     double x, double y, double z, double dx, double dy, double dz, RayLine & line, double sl,
     Sample & s, CellCache * cache)
 {
-        bool lay = !(line.valid && (fabs(sl) <= kLineRange)), again = lay;
-        if (!lay) {
+        bool serves = line.valid && (fabs(sl) <= kLineRange);
+        if (serves) {
                 f_line_eval(line, sl, s.lat, s.lon, s.alt);
                 d_classify<MODE, true>(v, ctx, s, cache);
-                const double clearance = fmin(fabs(s.alt - s.e0), fabs(s.alt - s.e1));
-                lay = !f_line_accurate(line, sl, clearance);
-                again = lay | !(clearance > line.tau);
+                serves = f_line_serves(line, sl, fmin(fabs(s.alt - s.e0), fabs(s.alt - s.e1)));
         }
-        if (again) {
-                f_to_geodetic(x, y, z, s.lat, s.lon, s.alt, &line, dx, dy, dz, lay);
+        if (!serves) {
+                f_to_geodetic(x, y, z, s.lat, s.lon, s.alt, &line, dx, dy, dz);
                 d_classify<MODE, true>(v, ctx, s, cache);
         }
-        return lay;
+        return !serves;
 }
 
 /* [ref stepper.c:799-813] tentative step length from the last sample */
@@ -1797,6 +1796,7 @@ struct PhaseIO {
         int creep_lanes;     /* the creep loop engages at or below this many live lanes */
         int lean;            /* lined pass: samples served by the line and the cached cell take the
                               * lean way (see LEAN in k_trace); 0: all through f_sample_on_line */
+        int slow_batch, slow_wait; /* ... and the others wait for company (see `slow` in k_trace) */
 };
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
@@ -1846,6 +1846,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         double dec_cx = -1., dec_cy = -1., dec_x0 = 0., dec_y0 = 0.;
         double z00 = 0., z10 = 0., z01 = 0., z11 = 0.;
         bool pending = false;
+        int slow_age = 0; /* wave-uniform: trips since a lane began to wait for the general way */
         unsigned pend_lo = 0, pend_hi = 0;
         int pend_ix = 0, pend_iy = 0;
 
@@ -2119,7 +2120,25 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 if (state == ST_STEP) line.s += t;
                         }
                 }
-                const bool slow = (ray >= 0) & !drain & !sampled & !waits;
+                /* The other samples go the general way (f_sample_on_line / d_sample).
+                 * In the lined pass that is a closed form plus a new line for the lane
+                 * -- 2.4 us of dependent arithmetic -- during which the rest of the wave
+                 * does nothing; each ray needs a few (its first sample, a new line
+                 * every few hundred metres, one at its crossing): one by one they
+                 * would cost a full wave several times what its lean samples cost.
+                 * So a lane that needs one WAITS (it takes no sample on this trip)
+                 * until kSlowBatch lanes do, or it has waited kSlowWait trips, or
+                 * nobody else is left to work for; when, not what, changes. */
+                bool slow = (ray >= 0) & !drain & !sampled & !waits;
+                if (LEAN && lean_ok) {
+                        const ull wants = __ballot(slow);
+                        const int n_wants = __popcll(wants), n_live = __popcll(__ballot(ray >= 0));
+                        slow_age = (wants != 0) ? slow_age + 1 : 0;
+                        const bool now = (n_wants >= ph.slow_batch) | (slow_age > ph.slow_wait) |
+                            (n_wants == n_live) | (n_live <= ph.creep_lanes);
+                        if (!now) waits = waits | slow, slow = false;
+                        if (now) slow_age = 0;
+                }
                 double qx = bx, qy = by, qz = bz;
                 if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
                         qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
@@ -2825,7 +2844,7 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         if (again) flags |= TRACE_CARRY_MEDIUM;
         const int resume = again ? 2 : 0;
         const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, nullptr, nullptr, 0, resume, pg, 0, 0,
-                kChunk, creep_lanes(n), 0 };
+                kChunk, creep_lanes(n), 0, 1, 0 };
         if (g_math_strict || !view.fast_ok)
                 return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
@@ -2852,14 +2871,15 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
                 const bool last = (k == tails);
                 PhaseIO a = { pg.ids, pg.n_in, last ? nullptr : list[k & 1], queue + 12 + k, lined, n_lined,
                         ((k > 0) && !last) ? quantum : 0, resume, pg, (k == 0) ? drain_lanes() : 0, park,
-                        kChunk, creep_lanes(n), 0 };
+                        kChunk, creep_lanes(n), 0, 1, 0 };
                 if (k > 0) a.ids = list[(k - 1) & 1], a.n_dev = queue + 12 + k - 1, a.accumulate = 1;
                 if (launch_trace<MODE, true, false>(view, n, again || (k > 0), pos, dir, max_steps, index,
                         length, n_steps, (k > 0) ? (flags | TRACE_CARRY_MEDIUM) : flags, a, stats, queue + k))
                         return 1;
         }
         const PhaseIO b = { lined, n_lined, nullptr, nullptr, nullptr, nullptr, 0, 1, pg, 0, park, kChunk,
-                creep_lanes(n), env_int("TURTLE_AMD_LEAN", 1) };
+                creep_lanes(n), env_int("TURTLE_AMD_LEAN", 1), env_int("TURTLE_AMD_SLOW_BATCH", 8),
+                env_int("TURTLE_AMD_SLOW_WAIT", 8) };
         return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
             n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 10);
 }
