@@ -1725,6 +1725,15 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
 
 /* ---- the hot kernel ---------------------------------------------------- */
 
+/* Diagnostic builds only (-DTAMD_PROFILE, scripts/exp_lined_profile.sh): what the
+ * waves of the lined pass spent their time on.  No product build contains it. */
+#ifdef TAMD_PROFILE
+__device__ ull g_prof[4096][8];
+#define PROF(stmt) do { if (MODEL) { stmt; } } while (0)
+#else
+#define PROF(stmt) do { } while (0)
+#endif
+
 constexpr int kChunk = 64; /* rays a wave draws from the global queue at once */
 constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many live lanes */
 constexpr int kCreepUnroll = 4; /* steps per trip of the one-map creep loop */
@@ -1763,20 +1772,19 @@ enum { TRACE_CARRY_MEDIUM = 1 };
 
 /* Launches in passes.  Steps per ray are heavy-tailed (C2: median 163, max
  * 11 327) and a ray's samples are sequential, so a launch lasts as long as its
- * last ray: one that STARTS late and is long decides.  A fast trace is therefore
- * cut two ways (run_trace):
- *  - in TIME SLICES: a closed-form pass steps a ray for at most `quantum` steps,
- *    then the ray goes back to the arrays and on a list (`parked`), and the next
- *    pass takes the list.  Every ray thus takes its k-th hundred of steps before
- *    any ray takes its (k+1)-th: no ray is still at its first steps when the
- *    others are done, whatever its place in the caller's order.
- *  - by ARITHMETIC: a ray that reaches `line_after` steps goes on the `lined`
- *    list; the last pass (MODEL) takes those to the end on their lines (see
- *    RayLine), ~7x cheaper per sample, in waves that hold nothing else.
+ * last ray.  A fast trace is therefore cut by ARITHMETIC (run_trace): the first
+ * pass takes every ray up to `line_after` steps by the closed form (2.4 us of
+ * dependent arithmetic a sample, which four waves per SIMD overlap) and puts a
+ * ray that gets there on the `lined` list; when its queue runs dry it hands over
+ * what its waves still hold (`parked`).  The last pass (MODEL) takes both lists
+ * to the end, a ray beyond `line_after` steps on its line (see RayLine: ~0.2 us a
+ * sample in the creep loop), packed into waves again.
  * Which arithmetic a sample uses depends only on the ray's own step count and
  * positions, never on scheduling; a ray that changes pass is sampled again where
  * it stands, by the same arithmetic as the sample it was handed over with:
- * results stay deterministic. */
+ * results stay deterministic.  (`quantum`: time slices for the closed-form
+ * pass -- measured, not used: a slice ends when its slowest wave does, and a
+ * sample's latency makes that 0.3 ms per 128 steps however few rays are left.) */
 struct PhaseIO {
         const int * ids;     /* the rays of this pass (NULL: slot == ray, all of them) */
         const ull * n_dev;   /* ... and their number, on the device */
@@ -1797,6 +1805,9 @@ struct PhaseIO {
         int lean;            /* lined pass: samples served by the line and the cached cell take the
                               * lean way (see LEAN in k_trace); 0: all through f_sample_on_line */
         int slow_batch, slow_wait; /* ... and the others wait for company (see `slow` in k_trace) */
+        int creep_wait;      /* groups of steps a stopped lane waits for company in the creep loop */
+        const int * ids2;    /* a second list, taken after `ids` (or NULL) */
+        const ull * n_dev2;
 };
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
@@ -1805,7 +1816,8 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
     int flags, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
 {
-        if (ph.n_dev != nullptr) n = (long)*ph.n_dev;
+        const long n_first = (ph.n_dev != nullptr) ? (long)*ph.n_dev : n; /* of the list `ids` */
+        if (ph.n_dev != nullptr) n = n_first + ((ph.n_dev2 != nullptr) ? (long)*ph.n_dev2 : 0);
         /* MODEL: besides its accumulated position B (bx, by, bz: the reference's
          * roundings, in every phase: see kLineTau0) a ray on its line carries
          * line.s, the path length from the point where the line was laid to B */
@@ -1826,16 +1838,14 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         OneCtx ctx;
         d_load_ctx<MODE, FAST>(v, ctx);
         CellCache cell = { ~0u, 0u, 0u, -1, nullptr };
-        /* LEAN (the lined pass over one map or one regular stack): the cached cell
+        /* LEAN (lined rays over one map or one regular stack): the cached cell
          * DECODED -- its node coordinates as doubles, its four elevations, the origin
          * of its tile -- so that a sample the line serves inside that cell needs no
          * load, no conversion between integers and doubles (a quarter of the rate of
-         * the other instructions) and none of the general lookup's cases; and a cell
-         * the lane has asked for and not yet received (`pending`: the loads fly
-         * while the other lanes take their samples; the lane takes its own one trip
-         * later).  Same values as f_grid_locate / f_grid_blend / f_stack_elevation
-         * produce: for an interior point (double)(int)hx == trunc(hx), and the clamp
-         * of the cell index does nothing. */
+         * the other instructions) and none of the general lookup's cases.  Same
+         * values as f_grid_locate / f_grid_blend / f_stack_elevation produce: for an
+         * interior point (double)(int)hx == trunc(hx), and the clamp of the cell
+         * index does nothing. */
         constexpr bool LEAN = MODEL && (MODE != TAMD_MODE_GENERIC);
         constexpr bool LEAN_STACK = (MODE == TAMD_MODE_ONE_STACK);
         const bool lean_ok = LEAN && (ph.lean != 0) && (!LEAN_STACK || (ctx.stack.regular != 0));
@@ -1845,10 +1855,20 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         unsigned dec_id = ~0u; /* the cell.id the decoded values stand for */
         double dec_cx = -1., dec_cy = -1., dec_x0 = 0., dec_y0 = 0.;
         double z00 = 0., z10 = 0., z01 = 0., z11 = 0.;
-        bool pending = false;
         int slow_age = 0; /* wave-uniform: trips since a lane began to wait for the general way */
-        unsigned pend_lo = 0, pend_hi = 0;
-        int pend_ix = 0, pend_iy = 0;
+/* the four elevations of the cached cell, as f_grid_blend decodes them */
+#define LEAN_DECODE_NODES()                                                                    \
+        do {                                                                                   \
+                if (lg.is_signed) {                                                            \
+                        z00 = (double)(int16_t)(cell.lo & 0xffffu), z10 = (double)((int)cell.lo >> 16); \
+                        z01 = (double)(int16_t)(cell.hi & 0xffffu), z11 = (double)((int)cell.hi >> 16); \
+                } else {                                                                       \
+                        z00 = (double)(cell.lo & 0xffffu), z10 = (double)(cell.lo >> 16);      \
+                        z01 = (double)(cell.hi & 0xffffu), z11 = (double)(cell.hi >> 16);      \
+                }                                                                              \
+                z00 = __builtin_fma(z00, lg.dz, lg.z0), z10 = __builtin_fma(z10, lg.dz, lg.z0); \
+                z01 = __builtin_fma(z01, lg.dz, lg.z0), z11 = __builtin_fma(z11, lg.dz, lg.z0); \
+        } while (0)
 
         long ray = -1;
         bool dead = false;
@@ -1858,6 +1878,10 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         int m = -1, k = -1, bm = -1, bk = -1, halvings = 0;
         int home = -1; /* CAN_FAULT: the tile of the ray's last sample (see Sample.slot) */
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_capped = 0;
+#ifdef TAMD_PROFILE
+        ull p_t0 = __builtin_amdgcn_s_memtime(), p_creep = 0, p_slow = 0;
+        unsigned p_iters = 0, p_groups = 0, p_slows = 0, p_fetches = 0, p_lanes = 0, p_entries = 0;
+#endif
 
         for (;;) {
                 /* ---- refill idle lanes from the queue ---- */
@@ -1888,7 +1912,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                         if (need && (rank < avail)) {
                                 ray = pool_next + rank;
-                                if (ph.ids != nullptr) ray = ph.ids[ray];
+                                if (ph.ids != nullptr) ray = (ray < n_first) ? ph.ids[ray] : ph.ids2[ray - n_first];
                                 if (MODEL) line.valid = false, line.s = 0., line.tau = kLineTau0;
                                 bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
                                 dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
@@ -1960,16 +1984,10 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
 
                 /* ---- LEAN: the decoded cell follows the cached one ---- */
                 if (LEAN && lean_ok) {
-                        const bool arrived = pending, moved = !pending & (cell.id != dec_id);
-                        if (__ballot(arrived | moved) != 0) {
-                                if (arrived) { /* the cell asked for on the last trip (same tile) */
-                                        const unsigned slot = LEAN_STACK ? (cell.id >> 24) : 0u;
-                                        cell.id = (slot << 24) | ((unsigned)pend_iy * (unsigned)lg.nx + (unsigned)pend_ix);
-                                        cell.lo = pend_lo, cell.hi = pend_hi;
-                                        dec_cx = (double)pend_ix, dec_cy = (double)pend_iy;
-                                        pending = false;
-                                }
+                        const bool moved = (cell.id != dec_id);
+                        if (__ballot(moved) != 0) {
                                 if (moved) { /* the general lookup moved the cache */
+                                        dec_id = cell.id;
                                         const bool cached = (cell.id != ~0u);
                                         const unsigned slot = LEAN_STACK ? (cell.id >> 24) : 0u;
                                         const unsigned cell_index = LEAN_STACK ? (cell.id & 0xffffffu) : cell.id;
@@ -1981,44 +1999,40 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         const unsigned cell_iy = cached ? cell_index / (unsigned)lg.nx : 0u;
                                         dec_cy = cached ? (double)cell_iy : -1.;
                                         dec_cx = cached ? (double)(cell_index - cell_iy * (unsigned)lg.nx) : -1.;
-                                }
-                                if (arrived | moved) {
-                                        dec_id = cell.id;
-                                        if (lg.is_signed) {
-                                                z00 = (double)(int16_t)(cell.lo & 0xffffu), z10 = (double)((int)cell.lo >> 16);
-                                                z01 = (double)(int16_t)(cell.hi & 0xffffu), z11 = (double)((int)cell.hi >> 16);
-                                        } else {
-                                                z00 = (double)(cell.lo & 0xffffu), z10 = (double)(cell.lo >> 16);
-                                                z01 = (double)(cell.hi & 0xffffu), z11 = (double)(cell.hi >> 16);
-                                        }
-                                        z00 = __builtin_fma(z00, lg.dz, lg.z0), z10 = __builtin_fma(z10, lg.dz, lg.z0);
-                                        z01 = __builtin_fma(z01, lg.dz, lg.z0), z11 = __builtin_fma(z11, lg.dz, lg.z0);
+                                        LEAN_DECODE_NODES();
                                 }
                         }
                 }
 
                 /* ---- creep loop, lean form ---------------------------------------
-                 * When a wave is down to a few rays, all stepping on their lines inside
-                 * their decoded cells, a step needs no state machine either.  What a
-                 * launch waits for in the end is ONE ray -- C2's longest takes 11 326
-                 * steps, most of them here, alone in its wave -- so what counts is the
-                 * latency of a trip, and a good part of that is the wave-wide question
-                 * "does any lane have to leave?" (compare, ballot, branch: the vector
-                 * and scalar units wait for each other).  It is asked once per
-                 * kCreepUnroll steps: a lane that cannot take one of them takes none of
-                 * the following either (nothing is committed from there on), and the
-                 * wave leaves after the group.  Same functions on the same values as
-                 * the general iteration: results do not depend on whether it engaged. */
-                if (LEAN && lean_ok && (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
+                 * A lined ray inside its decoded cell needs no state machine, no load
+                 * and no question asked to take a step.  This loop steps every lane
+                 * that can, in groups of kCreepUnroll steps (a lane that cannot take
+                 * one of them takes none of the following: nothing is committed from
+                 * there on), and asks the wave-wide question "who has stopped?"
+                 * (compare, ballot, branch: the vector and scalar units wait for each
+                 * other) once per group.  Lanes that stop -- another cell, a
+                 * bisection, a new line, no line yet -- need the general iteration
+                 * below, whose gathers and closed forms cost the wave thousands of
+                 * cycles whoever takes part: they WAIT for company.  The loop goes on
+                 * for the others until a quarter of the wave has stopped, or the first
+                 * to stop has waited ph.creep_wait groups; a wave down to a few rays
+                 * (ph.creep_lanes: what a launch ends with) serves a stopped lane at
+                 * once.  Same functions on the same values as the general iteration:
+                 * when a lane is served changes nothing of what it computes. */
+                if (LEAN && lean_ok) {
+                        PROF(p_creep -= __builtin_amdgcn_s_memtime(); p_entries++);
                         const tamd_grid & g = lg;
                         constexpr double guard = lean_guard;
                         const double mx = lean_mx, my = lean_my;
                         const double x0 = dec_x0, y0 = dec_y0, cx = dec_cx, cy = dec_cy;
+                        const int n_live = __popcll(__ballot(ray >= 0));
+                        int waited = 0;
                         for (int it = 0; it < 4096; it++) {
                                 /* no short-circuits below: every lane computes
                                  * everything (garbage is harmless, nothing is
                                  * committed on failure) and the tests are AND-ed */
-                                bool going = (ray >= 0) & (state == ST_STEP) & lined_ & line.valid & !pending;
+                                bool going = (ray >= 0) & (state == ST_STEP) & lined_ & line.valid;
 #pragma unroll
                                 for (int u = 0; u < kCreepUnroll; u++) {
                                         const double sl = line.s + ds;
@@ -2057,8 +2071,15 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         my_samples += going ? 1 : 0;
                                         ds = going ? ds_next : ds;
                                 }
-                                if (__ballot((ray >= 0) & !going) != 0) break;
+                                PROF(p_groups++);
+                                const int n_going = __popcll(__ballot(going));
+                                if (n_going == n_live) continue;
+                                waited++;
+                                if ((n_going == 0) | (n_live <= ph.creep_lanes) | (waited > ph.creep_wait) |
+                                    (4 * (n_live - n_going) >= n_live))
+                                        break;
                         }
+                        PROF(p_creep += __builtin_amdgcn_s_memtime());
                 }
 
                 /* `drain`: once the queue is dry a wave of phase A hands its rays over
@@ -2077,7 +2098,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                 if (state == ST_BISECT) t = 0.5 * (ds0 + ds1);
                 Sample s;
                 bool sampled = false; /* LEAN: the sample is in `s` already */
-                bool waits = false;   /* LEAN: the lane has asked for its cell: no sample on this trip */
                 if (LEAN && lean_ok) {
                         /* every lane computes everything (garbage is harmless: the
                          * flags decide what is used), as in the creep loop */
@@ -2090,26 +2110,28 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         const bool interior =
                             (hx > lean_guard) & (hx < lean_mx) & (hy > lean_guard) & (hy < lean_my);
                         const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);
+                        const bool here = can & (fabs(sl) <= kLineRange) & interior & (dec_cx >= 0.);
+                        /* another cell of the same tile: its nodes, now (the wave waits:
+                         * lanes come here in company, see the creep loop) */
+                        const bool fetch = here & !((tx == dec_cx) & (ty == dec_cy));
+                        if (__ballot(fetch) != 0) {
+                                PROF(p_fetches++);
+                                if (fetch) {
+                                        const unsigned slot = LEAN_STACK ? (cell.id >> 24) : 0u;
+                                        const uint16_t * nodes = LEAN_STACK ? ctx.slots[slot] : lg.nodes;
+                                        const int ix = (int)tx, iy = (int)ty;
+                                        d_cell_fetch(nodes, lg.nbx, ix, iy, cell.lo, cell.hi);
+                                        cell.id = (slot << 24) | ((unsigned)iy * (unsigned)lg.nx + (unsigned)ix);
+                                        dec_id = cell.id, dec_cx = tx, dec_cy = ty;
+                                        LEAN_DECODE_NODES();
+                                }
+                        }
                         const double fx_ = hx - tx, fy_ = hy - ty;
                         const double gx = 1. - fx_, gy = 1. - fy_;
                         const double elevation =
                             (z00 * gx * gy + z01 * gx * fy_ + z10 * fx_ * gy + z11 * fx_ * fy_) + ctx.offset;
                         const double clearance = fabs(alt - elevation);
-                        const bool here = can & (fabs(sl) <= kLineRange) & interior & (dec_cx >= 0.);
-                        const bool incell = (tx == dec_cx) & (ty == dec_cy);
-                        sampled = here & incell & f_line_serves(line, sl, clearance);
-                        /* another cell of the same tile: ask for its nodes, and take the
-                         * sample on the next trip (the wave does not wait for them now) */
-                        waits = here & !incell;
-                        if (__ballot(waits) != 0) {
-                                if (waits) {
-                                        const unsigned slot = LEAN_STACK ? (cell.id >> 24) : 0u;
-                                        const uint16_t * nodes = LEAN_STACK ? ctx.slots[slot] : lg.nodes;
-                                        pend_ix = (int)tx, pend_iy = (int)ty;
-                                        d_cell_fetch(nodes, lg.nbx, pend_ix, pend_iy, pend_lo, pend_hi);
-                                        pending = true;
-                                }
-                        }
+                        sampled = here & f_line_serves(line, sl, clearance);
                         if (sampled) {
                                 s.lat = lat, s.lon = lon, s.alt = alt;
                                 s.fault.centre = -1, s.slot = -1, s.k = 0;
@@ -2121,28 +2143,27 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         }
                 }
                 /* The other samples go the general way (f_sample_on_line / d_sample).
-                 * In the lined pass that is a closed form plus a new line for the lane
+                 * On a lined ray that is a closed form plus a new line for the lane
                  * -- 2.4 us of dependent arithmetic -- during which the rest of the wave
-                 * does nothing; each ray needs a few (its first sample, a new line
-                 * every few hundred metres, one at its crossing): one by one they
-                 * would cost a full wave several times what its lean samples cost.
-                 * So a lane that needs one WAITS (it takes no sample on this trip)
-                 * until kSlowBatch lanes do, or it has waited kSlowWait trips, or
-                 * nobody else is left to work for; when, not what, changes. */
-                bool slow = (ray >= 0) & !drain & !sampled & !waits;
-                if (LEAN && lean_ok) {
+                 * does nothing.  ph.slow_batch > 1: a lane that needs one waits (it takes
+                 * no sample on this trip) until that many lanes do, or it has waited
+                 * ph.slow_wait trips, or nobody else is left to work for. */
+                bool slow = (ray >= 0) & !drain & !sampled;
+                if (LEAN && lean_ok && (ph.slow_batch > 1)) {
                         const ull wants = __ballot(slow);
                         const int n_wants = __popcll(wants), n_live = __popcll(__ballot(ray >= 0));
                         slow_age = (wants != 0) ? slow_age + 1 : 0;
                         const bool now = (n_wants >= ph.slow_batch) | (slow_age > ph.slow_wait) |
                             (n_wants == n_live) | (n_live <= ph.creep_lanes);
-                        if (!now) waits = waits | slow, slow = false;
+                        if (!now) slow = false;
                         if (now) slow_age = 0;
                 }
                 double qx = bx, qy = by, qz = bz;
                 if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
                         qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
+                PROF(p_iters++; p_lanes += __popcll(__ballot(ray >= 0)));
                 if (__ballot(slow) != 0) {
+                        PROF(p_slows++; p_slow -= __builtin_amdgcn_s_memtime());
                         if (slow) {
                                 if (LINED) {
                                         /* B's parameter: -t on a new line (its origin is q),
@@ -2155,6 +2176,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
                                             (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr);
                         }
+                        PROF(p_slow += __builtin_amdgcn_s_memtime());
                 }
                 if ((ray >= 0) && !drain && (sampled | slow)) {
                         my_samples++;
@@ -2232,6 +2254,15 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                     (count >= ph.line_after);
                                 park = !MODEL & accept & !capped & !park_lined & (ph.quantum > 0) &
                                     (ph.parked != nullptr) & (count - count0 >= ph.quantum);
+                                if (MODEL && accept && !capped && !lined_ && (ph.line_after > 0) &&
+                                    (count >= ph.line_after)) {
+                                        /* from here on the ray steps on its line, laid by a
+                                         * fresh sample of its position -- what a ray handed
+                                         * over at this very step goes through */
+                                        lined_ = true;
+                                        line.valid = false, line.s = 0.;
+                                        state = ST_INIT;
+                                }
                                 located = (state == ST_BISECT) &
                                     (!(ds1 - ds0 > 1E-08) | (halvings > 1200));
                         }
@@ -2302,6 +2333,14 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                 }
         }
 
+#ifdef TAMD_PROFILE
+        if (MODEL && ((threadIdx.x & 63) == 0)) {
+                const unsigned w = (blockIdx.x * 4 + (threadIdx.x >> 6)) & 4095u;
+                g_prof[w][0] = __builtin_amdgcn_s_memtime() - p_t0, g_prof[w][1] = p_creep, g_prof[w][2] = p_slow;
+                g_prof[w][3] = ((ull)p_iters << 32) | p_groups, g_prof[w][4] = ((ull)p_slows << 32) | p_fetches;
+                g_prof[w][5] = p_lanes, g_prof[w][6] = (ull)count, g_prof[w][7] = p_entries;
+        }
+#endif
         block_tally(stats, my_rays, my_steps, my_samples, my_capped);
 }
 
@@ -2738,6 +2777,14 @@ static int trace_blocks_per_cu(const void * kernel)
         return blocks;
 }
 
+#ifdef TAMD_PROFILE
+extern "C" int tamd_dev_prof_read(unsigned long long * out) /* [4096][8] */
+{
+        HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)));
+        return 0;
+}
+#endif
+
 extern "C" void tamd_dev_math_set(int strict) { g_math_strict = strict ? 1 : 0; }
 extern "C" int tamd_dev_math_get(void) { return g_math_strict; }
 
@@ -2827,14 +2874,12 @@ static int drain_lanes(void)
 /* One round of a trace: all the rays (pg.ids == NULL), or the ones the last
  * round listed because they needed a tile (they carry on from the arrays).
  *
- * Fast arithmetic runs in passes (see PhaseIO): closed-form passes, each taking
- * the list the one before wrote, and the lined pass for the rays that reached
- * `park` steps.  A pass whose list is empty costs a launch of idle blocks (~5 us).
+ * Fast arithmetic runs in two passes (see PhaseIO): a closed-form pass over
+ * everything, and the lined pass over what is left of it.
  *
- * parked: room for 3 n ray ids (two lists the closed-form passes alternate
- * between, and the lined list); queue: TAMD_TRACE_COUNTERS words, zeroed:
- * [k] the work queue of pass k, [12 + k] the length of the list pass k wrote,
- * [11] the length of the lined list. */
+ * parked: room for 3 n ray ids (the lists); queue: TAMD_TRACE_COUNTERS words,
+ * zeroed: [0], [10] the work queues of the two passes, [12] the length of the list
+ * of rays handed over when the first one's queue ran dry, [11] of the lined list. */
 template <int MODE>
 static int run_trace(struct tamd_view view, long n, double * pos, const double * dir,
     int max_steps, int * index, double * length, int * n_steps, int flags, int * parked,
@@ -2844,7 +2889,7 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         if (again) flags |= TRACE_CARRY_MEDIUM;
         const int resume = again ? 2 : 0;
         const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, nullptr, nullptr, 0, resume, pg, 0, 0,
-                kChunk, creep_lanes(n), 0, 1, 0 };
+                kChunk, creep_lanes(n), 0, 1, 0, 0, nullptr, nullptr };
         if (g_math_strict || !view.fast_ok)
                 return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
@@ -2856,30 +2901,20 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         int * const list[2] = { parked, parked + n };
         int * const lined = parked + 2 * n;
         ull * const n_lined = queue + 11;
+        const int lean = env_int("TURTLE_AMD_LEAN", 1), slow_batch = env_int("TURTLE_AMD_SLOW_BATCH", 1);
+        const int slow_wait = env_int("TURTLE_AMD_SLOW_WAIT", 8), creep_wait = env_int("TURTLE_AMD_CREEP_WAIT", 4);
         /* pass 0: everything, up to `park` steps, handing over what it holds when its
-         * queue runs dry; then the TAIL passes over what was handed over (at most one
-         * ray per lane of the chip, all of them starting at once: nothing to refill
-         * with, so their waves thin out as rays end): in slices of `quantum` steps,
-         * each packing the survivors of the one before into full waves again */
-        const int quantum = (slice_quantum() < park) ? slice_quantum() : 0;
-        const int tails = (quantum > 0) ? (park + quantum - 1) / quantum : 1;
-        if (tails > 9) {
-                snprintf(g_error, sizeof(g_error), "TURTLE_AMD_QUANTUM is too small for TURTLE_AMD_PARK");
+         * queue runs dry (at most one ray per lane of the chip) */
+        const PhaseIO a = { pg.ids, pg.n_in, list[0], queue + 12, lined, n_lined, 0, resume, pg,
+                drain_lanes(), park, kChunk, creep_lanes(n), 0, 1, 0, 0, nullptr, nullptr };
+        if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length, n_steps,
+                flags, a, stats, queue))
                 return 1;
-        }
-        for (int k = 0; k <= tails; k++) {
-                const bool last = (k == tails);
-                PhaseIO a = { pg.ids, pg.n_in, last ? nullptr : list[k & 1], queue + 12 + k, lined, n_lined,
-                        ((k > 0) && !last) ? quantum : 0, resume, pg, (k == 0) ? drain_lanes() : 0, park,
-                        kChunk, creep_lanes(n), 0, 1, 0 };
-                if (k > 0) a.ids = list[(k - 1) & 1], a.n_dev = queue + 12 + k - 1, a.accumulate = 1;
-                if (launch_trace<MODE, true, false>(view, n, again || (k > 0), pos, dir, max_steps, index,
-                        length, n_steps, (k > 0) ? (flags | TRACE_CARRY_MEDIUM) : flags, a, stats, queue + k))
-                        return 1;
-        }
+        /* the last pass: the rays that reached `park` steps, then the ones handed over
+         * when the queue ran dry -- in that order, so that a wave draws rays of one
+         * kind (the second kind turns into the first at its `park`-th step) */
         const PhaseIO b = { lined, n_lined, nullptr, nullptr, nullptr, nullptr, 0, 1, pg, 0, park, kChunk,
-                creep_lanes(n), env_int("TURTLE_AMD_LEAN", 1), env_int("TURTLE_AMD_SLOW_BATCH", 8),
-                env_int("TURTLE_AMD_SLOW_WAIT", 8) };
+                creep_lanes(n), lean, slow_batch, slow_wait, creep_wait, list[0], queue + 12 };
         return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
             n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 10);
 }
