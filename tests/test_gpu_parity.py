@@ -502,7 +502,8 @@ def test_degenerate_inputs(math):
     g0, g1 = st.step(pos.copy(), None), st.step(pos.copy(), d)
     gt = st.trace(pos.copy(), d, max_steps=600)
     assert np.array_equal(g0["index"], r0["index"]) and np.array_equal(g1["index"], r1["index"])
-    assert np.array_equal(gt["index"], rt["index"]) and np.array_equal(gt["n_steps"], rt["n_steps"])
+    assert np.array_equal(gt["index"], rt["index"]), (gt["index"], rt["index"])
+    assert np.array_equal(gt["n_steps"], rt["n_steps"]), (gt["n_steps"], rt["n_steps"])
     ok = np.isfinite(r1["step"])
     assert np.array_equal(np.isfinite(g1["step"]), ok)
     assert np.abs(g1["step"][ok] - r1["step"][ok]).max() <= 1e-6 * np.abs(r1["step"][ok]).max()

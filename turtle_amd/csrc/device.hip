@@ -577,43 +577,48 @@ __device__ __noinline__ void d_unproject(
 
 /* ---- one grid --------------------------------------------------------- */
 
-/* Where node (ix, iy) sits in HBM: the grid is stored in blocks of 8 x 8 nodes
- * (128 bytes = one cache line: internal.h), so that the four nodes of a cell --
- * and the cells a ray visits next, whichever way it heads -- share a line far
- * more often than in rows of 7 KB. */
-__device__ __forceinline__ unsigned d_node_index(int nbx, int ix, int iy)
+/* Where the nodes sit in HBM: in BLOCKS of 8 x 8 nodes = 7 x 7 cells = 128 bytes
+ * = one cache line (internal.h), block (bx, by) holding nodes 7 bx .. 7 bx + 7 by
+ * 7 by .. 7 by + 7: neighbouring blocks share a row / column of nodes, so that
+ * the four nodes of ANY cell are in one block -- one line, one request to the
+ * memory system whichever cell -- and the ~7 cells a ray crosses next are in it
+ * too.  (1.31 x the bytes of the plain grid.) */
+__device__ __forceinline__ void d_block_of(int nbx, int ix, int iy, unsigned & block, unsigned & lx,
+    unsigned & ly)
 {
-        return (((unsigned)iy >> 3) * (unsigned)nbx + ((unsigned)ix >> 3)) * 64u +
-            (((unsigned)iy & 7u) << 3) + ((unsigned)ix & 7u);
+        /* a cell's lower-left node: ix <= nx - 2, so ix / 7 < nbx = ceil((nx - 1) / 7) */
+        const unsigned bx = (unsigned)ix / TAMD_BLOCK_CELLS, by = (unsigned)iy / TAMD_BLOCK_CELLS;
+        lx = (unsigned)ix - bx * TAMD_BLOCK_CELLS, ly = (unsigned)iy - by * TAMD_BLOCK_CELLS;
+        block = by * (unsigned)nbx + bx;
+}
+
+/* a single node, wherever (the last row / column of a grid is only in the last block) */
+__device__ __forceinline__ size_t d_node_index(const tamd_grid & g, int ix, int iy)
+{
+        const unsigned bx = min((unsigned)ix / TAMD_BLOCK_CELLS, (unsigned)g.nbx - 1u);
+        const unsigned by = min((unsigned)iy / TAMD_BLOCK_CELLS, (unsigned)g.nby - 1u);
+        const unsigned lx = (unsigned)ix - bx * TAMD_BLOCK_CELLS, ly = (unsigned)iy - by * TAMD_BLOCK_CELLS;
+        return ((size_t)by * (unsigned)g.nbx + bx) * 64u + ly * 8u + lx;
 }
 
 /* the four raw nodes of cell (ix, iy): lo = z00 | z10 << 16, hi = z01 | z11 << 16.
- * One index computation; the upper row is +8 inside a block, or a jump to the
- * next block row.  The two nodes of a row are neighbours in memory except in a
- * block's last column: one 32-bit load (2-byte aligned) fetches both, and only
- * the lanes in a last column (1 in 8) go back for the node of the next block.
- * Per wave that is ~144 line look-ups in the vector L1 instead of 256 -- the
- * gathers are most of what a batch of single steps asks of it.  (The pair load
- * never overruns the array: a cell's left-hand nodes have ix <= nx - 2, which
- * is never the last node of the last block.) */
+ * The two nodes of a row are neighbours in the block: one 32-bit load (2-byte
+ * aligned) fetches both, the row above is 16 bytes on. */
 typedef unsigned __attribute__((aligned(2))) u32_a2;
 typedef const __attribute__((address_space(1))) u32_a2 * global_pair_t;
 
 __device__ __forceinline__ void d_cell_fetch(
     const uint16_t * nodes, int nbx, int ix, int iy, unsigned & lo, unsigned & hi)
 {
-        global_nodes_t p = GLOBAL_NODES(nodes) + d_node_index(nbx, ix, iy);
-        const unsigned up = (((unsigned)iy & 7u) == 7u) ? (unsigned)nbx * 64u - 56u : 8u;
-        lo = *(global_pair_t)p, hi = *(global_pair_t)(p + up);
-        if (((unsigned)ix & 7u) == 7u) { /* 64 - 7: the next block's first column */
-                const unsigned z10 = p[57], z11 = p[up + 57];
-                lo = (lo & 0xffffu) | (z10 << 16), hi = (hi & 0xffffu) | (z11 << 16);
-        }
+        unsigned block, lx, ly;
+        d_block_of(nbx, ix, iy, block, lx, ly);
+        global_nodes_t p = GLOBAL_NODES(nodes) + ((size_t)block * 64u + ly * 8u + lx);
+        lo = *(global_pair_t)p, hi = *(global_pair_t)(p + 8);
 }
 
 __device__ __forceinline__ double d_node(const tamd_grid & g, int ix, int iy)
 {
-        const uint16_t raw = GLOBAL_NODES(g.nodes)[d_node_index(g.nbx, ix, iy)];
+        const uint16_t raw = GLOBAL_NODES(g.nodes)[d_node_index(g, ix, iy)];
         const double v = g.is_signed ? (double)(int16_t)raw : (double)raw;
         return g.z0 + v * g.dz; /* [ref map.c:41-44]; exact for z0=0, dz=1 */
 }
@@ -631,7 +636,61 @@ struct CellCache {
          * dependent pointer load of every sample that stays in the tile) */
         int slot;
         const uint16_t * tile;
+        /* the BLOCK the last fetch fell in, staged whole in the lane's 128 bytes of
+         * LDS (see BlockStage): (tile slot << 24 | block), or ~0u when empty; and
+         * where those bytes are (~0u: the kernel stages nothing) */
+        unsigned block, lds;
 };
+#define CELL_CACHE_EMPTY(lds_at) { ~0u, 0u, 0u, -1, nullptr, ~0u, (lds_at) }
+
+/* Each lane of a trace kernel keeps the 128-byte block of its last fetch in LDS:
+ * a ray crosses ~7 cells of a block before it leaves it, and every one of them
+ * would otherwise be a miss in the vector L1 (32 KB for the 1 024 rays of a CU:
+ * nothing survives there) -- it is the rate of those misses, ~64 in flight per CU
+ * at ~1 200 cycles each, that bounds the bulk of a trace, not the arithmetic
+ * (DESIGN.md 3.1).  Staging is by LDS-DMA, one 16-byte row per lane and
+ * instruction (global_load_lds_dwordx4: destination = wave-uniform base + lane
+ * x 16, source per lane), eight instructions per block; the image of a wave is
+ * [row][lane][16 bytes], 8 KB, four waves to a workgroup. */
+struct BlockStage {
+        __device__ static unsigned lane_at()
+        {
+                return (threadIdx.x >> 6) * 8192u + (threadIdx.x & 63u) * 16u;
+        }
+};
+typedef __attribute__((address_space(3))) unsigned char * lds_bytes_t;
+typedef const __attribute__((address_space(3))) unsigned * lds_words_t;
+
+/* the raw nodes of cell (ix, iy) of the grid at `nodes` through a lane's cache */
+__device__ __forceinline__ void d_cell_get(const uint16_t * nodes, int nbx, int ix, int iy,
+    unsigned key, CellCache & c, unsigned & lo, unsigned & hi)
+{
+        if (c.lds == ~0u) {
+                d_cell_fetch(nodes, nbx, ix, iy, lo, hi);
+                return;
+        }
+        unsigned block, lx, ly;
+        d_block_of(nbx, ix, iy, block, lx, ly);
+        extern __shared__ __attribute__((aligned(16))) unsigned char block_stage_[];
+        if ((key | block) != c.block) {
+                const char * src = (const char *)(nodes + (size_t)block * 64u);
+                lds_bytes_t wave = (lds_bytes_t)block_stage_ + (threadIdx.x >> 6) * 8192u;
+#pragma unroll
+                for (int row = 0; row < 8; row++)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 16 * row),
+                            (__attribute__((address_space(3))) void *)(wave + 1024 * row), 16, 0, 0);
+                /* the compiler does not order LDS reads behind an LDS-DMA */
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                c.block = key | block;
+        }
+        /* rows ly and ly + 1, nodes lx and lx + 1: the aligned words that hold them
+         * (the word after a row's last is the next lane's: read, not used) */
+        lds_words_t w = (lds_words_t)((lds_bytes_t)block_stage_ + c.lds + ly * 1024u + (lx >> 1) * 4u);
+        const unsigned a0 = w[0], a1 = w[1], b0 = w[256], b1 = w[257];
+        const unsigned shift = (lx & 1u) * 16u;
+        lo = (unsigned)((((ull)a1 << 32) | a0) >> shift);
+        hi = (unsigned)((((ull)b1 << 32) | b0) >> shift);
+}
 
 /* [ref map.c:229-277], fast-math form.  Differences from the strict form, none
  * of which changes an elevation by more than ~1e-12 m: (x - x0) is multiplied
@@ -693,8 +752,11 @@ __device__ __forceinline__ bool f_grid_elevation(
         if ((cache != nullptr) && (cache->id == c.id)) {
                 lo = cache->lo, hi = cache->hi;
         } else {
-                d_cell_fetch(g.nodes, g.nbx, c.ix, c.iy, lo, hi);
-                if (cache != nullptr) cache->id = c.id, cache->lo = lo, cache->hi = hi;
+                if (cache != nullptr) {
+                        d_cell_get(g.nodes, g.nbx, c.ix, c.iy, 0u, *cache, lo, hi);
+                        cache->id = c.id, cache->lo = lo, cache->hi = hi;
+                } else
+                        d_cell_fetch(g.nodes, g.nbx, c.ix, c.iy, lo, hi);
         }
         z = f_grid_blend(g, c, lo, hi);
         return c.inside;
@@ -980,9 +1042,11 @@ __device__ __forceinline__ int f_stack_elevation(const tamd_view & v,
                         if ((cache != nullptr) && (cache->id == id)) {
                                 lo = cache->lo, hi = cache->hi;
                         } else {
-                                d_cell_fetch(nodes, p.nbx, ix, iy, lo, hi);
-                                if (cache != nullptr)
+                                if (cache != nullptr) {
+                                        d_cell_get(nodes, p.nbx, ix, iy, (unsigned)slot << 24, *cache, lo, hi);
                                         cache->id = id, cache->lo = lo, cache->hi = hi;
+                                } else
+                                        d_cell_fetch(nodes, p.nbx, ix, iy, lo, hi);
                         }
                         double z00, z10, z01, z11;
                         if (p.is_signed) {
@@ -1662,7 +1726,7 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
                 double px = pos[3 * r], py = pos[3 * r + 1], pz = pos[3 * r + 2];
                 const double dx = dir[3 * r], dy = dir[3 * r + 1], dz = dir[3 * r + 2];
                 const int medium0 = index[2 * r];
-                CellCache cell = { ~0u, 0u, 0u, -1, nullptr };
+                CellCache cell = CELL_CACHE_EMPTY(~0u);
                 CellCache * cache = (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr;
                 Sample s;
                 /* fast math: the bracket is a segment of the ray behind q, so the
@@ -1837,7 +1901,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         bool exhausted = false;            /* wave-uniform */
         OneCtx ctx;
         d_load_ctx<MODE, FAST>(v, ctx);
-        CellCache cell = { ~0u, 0u, 0u, -1, nullptr };
+        CellCache cell = CELL_CACHE_EMPTY((FAST && (MODE != TAMD_MODE_GENERIC)) ? BlockStage::lane_at() : ~0u);
         /* LEAN (lined rays over one map or one regular stack): the cached cell
          * DECODED -- its node coordinates as doubles, its four elevations, the origin
          * of its tile -- so that a sample the line serves inside that cell needs no
@@ -2061,9 +2125,10 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         double ds_next = clearance * v.slope;
                                         if (ds_next < v.resolution) ds_next = v.resolution;
                                         /* B += d * ds, as the general iteration does it (a
-                                         * lane that is not going adds d * 0: B itself) */
-                                        const double moved = going ? ds : 0.;
-                                        bx = bx + dx * moved, by = by + dy * moved, bz = bz + dz * moved;
+                                         * select, not d * 0: the direction of a lane that is
+                                         * not going may be anything, NaN included) */
+                                        bx = going ? bx + dx * ds : bx, by = going ? by + dy * ds : by;
+                                        bz = going ? bz + dz * ds : bz;
                                         line.tau = going ? line.tau + kLineDrift : line.tau;
                                         line.s = going ? sl : line.s;
                                         len = going ? len + ds : len;
@@ -2120,7 +2185,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         const unsigned slot = LEAN_STACK ? (cell.id >> 24) : 0u;
                                         const uint16_t * nodes = LEAN_STACK ? ctx.slots[slot] : lg.nodes;
                                         const int ix = (int)tx, iy = (int)ty;
-                                        d_cell_fetch(nodes, lg.nbx, ix, iy, cell.lo, cell.hi);
+                                        d_cell_get(nodes, lg.nbx, ix, iy, slot << 24, cell, cell.lo, cell.hi);
                                         cell.id = (slot << 24) | ((unsigned)iy * (unsigned)lg.nx + (unsigned)ix);
                                         dec_id = cell.id, dec_cx = tx, dec_cy = ty;
                                         LEAN_DECODE_NODES();
@@ -2762,10 +2827,10 @@ extern "C" int tamd_k_step(struct tamd_view view, long n, double * pos,
  * with a dependent 4-node gather per sample, so a few waves per SIMD are
  * enough to cover the gather latency; TURTLE_AMD_TRACE_WAVES overrides the
  * default for experiments. */
-static int trace_blocks_per_cu(const void * kernel)
+static int trace_blocks_per_cu(const void * kernel, size_t lds)
 {
         int blocks = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 256, 0) !=
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 256, lds) !=
                 hipSuccess ||
             blocks < 1)
                 blocks = 1;
@@ -2794,7 +2859,9 @@ static int launch_trace_(struct tamd_view view, long n, bool n_on_device, double
     int flags, PhaseIO ph, ull * stats, ull * queue)
 {
         const void * kernel = (const void *)k_trace<MODE, FAST, MODEL, PAGED>;
-        long blocks = (long)g_cus * trace_blocks_per_cu(kernel);
+        /* the lanes' staged blocks (BlockStage): 128 bytes each, and a word to spare */
+        const size_t lds = (FAST && (MODE != TAMD_MODE_GENERIC)) ? 256 * 128 + 16 : 0;
+        long blocks = (long)g_cus * trace_blocks_per_cu(kernel, lds);
         const long useful = (n + 255) / 256;
         if (!n_on_device && (blocks > useful)) blocks = useful;
         if (n_on_device) {
@@ -2813,7 +2880,7 @@ static int launch_trace_(struct tamd_view view, long n, bool n_on_device, double
                 if (blocks > wide) blocks = wide;
         }
         hipLaunchKernelGGL((k_trace<MODE, FAST, MODEL, PAGED>), dim3((unsigned)blocks), dim3(256),
-            0, g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, ph, stats,
+            lds, g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, ph, stats,
             queue);
         LAUNCH_CHECK("k_trace");
         return 0;

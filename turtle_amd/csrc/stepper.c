@@ -334,7 +334,9 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
                 struct tamd_stack * t = &stacks[i];
                 const int slots = t->nlat * t->nlon;
                 const struct tamd_grid * proto = NULL;
-                int regular = (slots > 0) && (slots <= 255);
+                /* slot and cell share a 32-bit id in the lanes' caches (slot << 24 |
+                 * cell, ~0u: empty): at most 254 slots of at most 2^24 cells */
+                int regular = (slots > 0) && (slots <= 254);
                 t->nodes_first = t->tile_first;
                 for (j = 0; j < slots; j++) {
                         const int g = tiles[t->tile_first + j];
@@ -342,7 +344,7 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
                         if (g < 0) continue;
                         const struct tamd_grid * q = &h_grids[g];
                         if (proto == NULL) proto = q;
-                        if ((q->nx != proto->nx) || (q->ny != proto->ny) ||
+                        if (((size_t)q->nx * (size_t)q->ny > ((size_t)1 << 24)) || (q->nx != proto->nx) || (q->ny != proto->ny) ||
                             (q->dx != proto->dx) || (q->dy != proto->dy) ||
                             (q->z0 != proto->z0) || (q->dz != proto->dz) ||
                             (q->is_signed != proto->is_signed) ||
