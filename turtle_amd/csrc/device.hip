@@ -256,34 +256,15 @@ __device__ __forceinline__ double f_atan2(double y, double x)
  * serves ~1000 samples.  Whether a sample comes from the line depends on the
  * ray alone (its own line and path parameter), never on its wave. */
 constexpr double kLineRange = 4000.; /* m, either side of the origin: hard limit */
-constexpr double kLineTolerance = 2e-10; /* see f_line_accurate */
-/* A ray's position is ACCUMULATED step by step, B += d * ds with the reference's
- * roundings [ref stepper.c:824, :862-863], in every phase: each step leaves B
- * up to half an ulp of 6.4e6 m per coordinate (8e-10 m) off the straight line,
- * mostly the same way from step to step (a skimming ray adds the same increment
- * thousands of times: 2.7e-6 m measured over the 11 326 steps of C2's longest
- * ray) -- and the reference decides on ITS positions.  The line is a function of
- * the path length alone, so a sample taken from it answers for the ideal point
- * O + d * s, which is off the reference's by that drift.  That is harmless where
- * it only sizes the next step, and decisive where the medium is decided within
- * the drift of the boundary (a ray tangent to the ground: one step more or
- * less is 1e-2 m of path).  So the line keeps count of what its truncation and
- * the drift since it was laid can amount to (tau: kLineTau0 at the origin +
- * kLineDrift per accepted step), and a sample whose clearance is not above it is
- * taken again by the closed form AT THE ACCUMULATED POSITION, as the closed-form
- * passes would -- which lays a new line there, whose drift starts from nothing
- * (the samples of a bisection all leave from one accumulated position: the line
- * laid at the first of them that is too close to call serves the others). */
-constexpr double kLineTau0 = 1e-9;  /* m: the truncation allowed near a boundary (2e-10 m) and
-                                     * the rounding of latitude and longitude (8e-10 m on the
-                                     * ground, a third of that in elevation) */
-constexpr double kLineDrift = 1e-9; /* m per step: (3 x (2^-31)^2)^0.5 = 8.1e-10 rounded up */
+constexpr double kLineTolerance = 2e-10; /* see f_line_serves */
+constexpr double kLineTau0 = 1e-9;
+constexpr double kLineDrift = 1e-9;
 
 struct RayLine {
         double s;                /* path parameter of the ray's position B */
         double lat[4], lon[4], alt[4]; /* degrees, degrees, metres; [k]: s^k */
         double c4;               /* bound on the neglected term: c4 s^4 metres */
-        double tau;              /* clearance below which the closed form decides (above) */
+        double tau;
         bool valid;
 };
 
@@ -293,16 +274,10 @@ struct RayLine {
  * from any boundary, below 2e-10 OF the clearance: all such a sample decides
  * is the length of the next step, to the same relative accuracy.  At latitude
  * 45 this lets a line serve 500 m near the ground and ~2 km in free flight. */
-__device__ __forceinline__ bool f_line_accurate(const RayLine & L, double s, double clearance)
-{
-        const double s2 = s * s;
-        return L.c4 * s2 * s2 <= kLineTolerance * fmax(clearance, 1.);
-}
-
-/* ... and the sample is not within the line's drift of a boundary (kLineTau0) */
 __device__ __forceinline__ bool f_line_serves(const RayLine & L, double s, double clearance)
 {
-        return f_line_accurate(L, s, clearance) & (clearance > L.tau);
+        const double s2 = s * s;
+        return (L.c4 * s2 * s2 <= kLineTolerance * fmax(clearance, 1.)) & (clearance > L.tau);
 }
 
 __device__ __forceinline__ void f_line_eval(const RayLine & L, double s, double & latitude,
@@ -577,48 +552,43 @@ __device__ __noinline__ void d_unproject(
 
 /* ---- one grid --------------------------------------------------------- */
 
-/* Where the nodes sit in HBM: in BLOCKS of 8 x 8 nodes = 7 x 7 cells = 128 bytes
- * = one cache line (internal.h), block (bx, by) holding nodes 7 bx .. 7 bx + 7 by
- * 7 by .. 7 by + 7: neighbouring blocks share a row / column of nodes, so that
- * the four nodes of ANY cell are in one block -- one line, one request to the
- * memory system whichever cell -- and the ~7 cells a ray crosses next are in it
- * too.  (1.31 x the bytes of the plain grid.) */
-__device__ __forceinline__ void d_block_of(int nbx, int ix, int iy, unsigned & block, unsigned & lx,
-    unsigned & ly)
+/* Where node (ix, iy) sits in HBM: the grid is stored in blocks of 8 x 8 nodes
+ * (128 bytes = one cache line: internal.h), so that the four nodes of a cell --
+ * and the cells a ray visits next, whichever way it heads -- share a line far
+ * more often than in rows of 7 KB. */
+__device__ __forceinline__ unsigned d_node_index(int nbx, int ix, int iy)
 {
-        /* a cell's lower-left node: ix <= nx - 2, so ix / 7 < nbx = ceil((nx - 1) / 7) */
-        const unsigned bx = (unsigned)ix / TAMD_BLOCK_CELLS, by = (unsigned)iy / TAMD_BLOCK_CELLS;
-        lx = (unsigned)ix - bx * TAMD_BLOCK_CELLS, ly = (unsigned)iy - by * TAMD_BLOCK_CELLS;
-        block = by * (unsigned)nbx + bx;
-}
-
-/* a single node, wherever (the last row / column of a grid is only in the last block) */
-__device__ __forceinline__ size_t d_node_index(const tamd_grid & g, int ix, int iy)
-{
-        const unsigned bx = min((unsigned)ix / TAMD_BLOCK_CELLS, (unsigned)g.nbx - 1u);
-        const unsigned by = min((unsigned)iy / TAMD_BLOCK_CELLS, (unsigned)g.nby - 1u);
-        const unsigned lx = (unsigned)ix - bx * TAMD_BLOCK_CELLS, ly = (unsigned)iy - by * TAMD_BLOCK_CELLS;
-        return ((size_t)by * (unsigned)g.nbx + bx) * 64u + ly * 8u + lx;
+        return (((unsigned)iy >> 3) * (unsigned)nbx + ((unsigned)ix >> 3)) * 64u +
+            (((unsigned)iy & 7u) << 3) + ((unsigned)ix & 7u);
 }
 
 /* the four raw nodes of cell (ix, iy): lo = z00 | z10 << 16, hi = z01 | z11 << 16.
- * The two nodes of a row are neighbours in the block: one 32-bit load (2-byte
- * aligned) fetches both, the row above is 16 bytes on. */
+ * One index computation; the upper row is +8 inside a block, or a jump to the
+ * next block row.  The two nodes of a row are neighbours in memory except in a
+ * block's last column: one 32-bit load (2-byte aligned) fetches both, and only
+ * the lanes in a last column (1 in 8) go back for the node of the next block.
+ * Per wave that is ~144 line look-ups in the vector L1 instead of 256 -- the
+ * gathers are most of what a batch of single steps asks of it.  (The pair load
+ * never overruns the array: a cell's left-hand nodes have ix <= nx - 2, which
+ * is never the last node of the last block.) */
 typedef unsigned __attribute__((aligned(2))) u32_a2;
 typedef const __attribute__((address_space(1))) u32_a2 * global_pair_t;
 
 __device__ __forceinline__ void d_cell_fetch(
     const uint16_t * nodes, int nbx, int ix, int iy, unsigned & lo, unsigned & hi)
 {
-        unsigned block, lx, ly;
-        d_block_of(nbx, ix, iy, block, lx, ly);
-        global_nodes_t p = GLOBAL_NODES(nodes) + ((size_t)block * 64u + ly * 8u + lx);
-        lo = *(global_pair_t)p, hi = *(global_pair_t)(p + 8);
+        global_nodes_t p = GLOBAL_NODES(nodes) + d_node_index(nbx, ix, iy);
+        const unsigned up = (((unsigned)iy & 7u) == 7u) ? (unsigned)nbx * 64u - 56u : 8u;
+        lo = *(global_pair_t)p, hi = *(global_pair_t)(p + up);
+        if (((unsigned)ix & 7u) == 7u) { /* 64 - 7: the next block's first column */
+                const unsigned z10 = p[57], z11 = p[up + 57];
+                lo = (lo & 0xffffu) | (z10 << 16), hi = (hi & 0xffffu) | (z11 << 16);
+        }
 }
 
 __device__ __forceinline__ double d_node(const tamd_grid & g, int ix, int iy)
 {
-        const uint16_t raw = GLOBAL_NODES(g.nodes)[d_node_index(g, ix, iy)];
+        const uint16_t raw = GLOBAL_NODES(g.nodes)[d_node_index(g.nbx, ix, iy)];
         const double v = g.is_signed ? (double)(int16_t)raw : (double)raw;
         return g.z0 + v * g.dz; /* [ref map.c:41-44]; exact for z0=0, dz=1 */
 }
@@ -636,61 +606,7 @@ struct CellCache {
          * dependent pointer load of every sample that stays in the tile) */
         int slot;
         const uint16_t * tile;
-        /* the BLOCK the last fetch fell in, staged whole in the lane's 128 bytes of
-         * LDS (see BlockStage): (tile slot << 24 | block), or ~0u when empty; and
-         * where those bytes are (~0u: the kernel stages nothing) */
-        unsigned block, lds;
 };
-#define CELL_CACHE_EMPTY(lds_at) { ~0u, 0u, 0u, -1, nullptr, ~0u, (lds_at) }
-
-/* Each lane of a trace kernel keeps the 128-byte block of its last fetch in LDS:
- * a ray crosses ~7 cells of a block before it leaves it, and every one of them
- * would otherwise be a miss in the vector L1 (32 KB for the 1 024 rays of a CU:
- * nothing survives there) -- it is the rate of those misses, ~64 in flight per CU
- * at ~1 200 cycles each, that bounds the bulk of a trace, not the arithmetic
- * (DESIGN.md 3.1).  Staging is by LDS-DMA, one 16-byte row per lane and
- * instruction (global_load_lds_dwordx4: destination = wave-uniform base + lane
- * x 16, source per lane), eight instructions per block; the image of a wave is
- * [row][lane][16 bytes], 8 KB, four waves to a workgroup. */
-struct BlockStage {
-        __device__ static unsigned lane_at()
-        {
-                return (threadIdx.x >> 6) * 8192u + (threadIdx.x & 63u) * 16u;
-        }
-};
-typedef __attribute__((address_space(3))) unsigned char * lds_bytes_t;
-typedef const __attribute__((address_space(3))) unsigned * lds_words_t;
-
-/* the raw nodes of cell (ix, iy) of the grid at `nodes` through a lane's cache */
-__device__ __forceinline__ void d_cell_get(const uint16_t * nodes, int nbx, int ix, int iy,
-    unsigned key, CellCache & c, unsigned & lo, unsigned & hi)
-{
-        if (c.lds == ~0u) {
-                d_cell_fetch(nodes, nbx, ix, iy, lo, hi);
-                return;
-        }
-        unsigned block, lx, ly;
-        d_block_of(nbx, ix, iy, block, lx, ly);
-        extern __shared__ __attribute__((aligned(16))) unsigned char block_stage_[];
-        if ((key | block) != c.block) {
-                const char * src = (const char *)(nodes + (size_t)block * 64u);
-                lds_bytes_t wave = (lds_bytes_t)block_stage_ + (threadIdx.x >> 6) * 8192u;
-#pragma unroll
-                for (int row = 0; row < 8; row++)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 16 * row),
-                            (__attribute__((address_space(3))) void *)(wave + 1024 * row), 16, 0, 0);
-                /* the compiler does not order LDS reads behind an LDS-DMA */
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                c.block = key | block;
-        }
-        /* rows ly and ly + 1, nodes lx and lx + 1: the aligned words that hold them
-         * (the word after a row's last is the next lane's: read, not used) */
-        lds_words_t w = (lds_words_t)((lds_bytes_t)block_stage_ + c.lds + ly * 1024u + (lx >> 1) * 4u);
-        const unsigned a0 = w[0], a1 = w[1], b0 = w[256], b1 = w[257];
-        const unsigned shift = (lx & 1u) * 16u;
-        lo = (unsigned)((((ull)a1 << 32) | a0) >> shift);
-        hi = (unsigned)((((ull)b1 << 32) | b0) >> shift);
-}
 
 /* [ref map.c:229-277], fast-math form.  Differences from the strict form, none
  * of which changes an elevation by more than ~1e-12 m: (x - x0) is multiplied
@@ -752,11 +668,8 @@ __device__ __forceinline__ bool f_grid_elevation(
         if ((cache != nullptr) && (cache->id == c.id)) {
                 lo = cache->lo, hi = cache->hi;
         } else {
-                if (cache != nullptr) {
-                        d_cell_get(g.nodes, g.nbx, c.ix, c.iy, 0u, *cache, lo, hi);
-                        cache->id = c.id, cache->lo = lo, cache->hi = hi;
-                } else
-                        d_cell_fetch(g.nodes, g.nbx, c.ix, c.iy, lo, hi);
+                d_cell_fetch(g.nodes, g.nbx, c.ix, c.iy, lo, hi);
+                if (cache != nullptr) cache->id = c.id, cache->lo = lo, cache->hi = hi;
         }
         z = f_grid_blend(g, c, lo, hi);
         return c.inside;
@@ -1042,11 +955,9 @@ __device__ __forceinline__ int f_stack_elevation(const tamd_view & v,
                         if ((cache != nullptr) && (cache->id == id)) {
                                 lo = cache->lo, hi = cache->hi;
                         } else {
-                                if (cache != nullptr) {
-                                        d_cell_get(nodes, p.nbx, ix, iy, (unsigned)slot << 24, *cache, lo, hi);
+                                d_cell_fetch(nodes, p.nbx, ix, iy, lo, hi);
+                                if (cache != nullptr)
                                         cache->id = id, cache->lo = lo, cache->hi = hi;
-                                } else
-                                        d_cell_fetch(nodes, p.nbx, ix, iy, lo, hi);
                         }
                         double z00, z10, z01, z11;
                         if (p.is_signed) {
@@ -1217,12 +1128,11 @@ __device__ __forceinline__ void d_sample(const tamd_view & v, const OneCtx & ctx
         d_classify<MODE, FAST>(v, ctx, s, cache);
 }
 
-/* A sample of a ray that carries a line: at (x, y, z) -- the ray's accumulated
- * position, moved by the tentative length -- which is parameter sl of the line.
- * Taken from the line if it serves (f_line_serves); else by the closed form at
- * (x, y, z), which lays a new line through the point (origin there: the caller
- * re-bases its path parameter), and true is returned.  Which of the two happens
- * depends on the ray's own line, position and sample only. */
+/* A sample of a ray that carries a line: at (x, y, z), which is parameter sl
+ * of the line.  Taken from the line if it serves; else by the closed form,
+ * which lays a new line through the point (origin there: the caller re-bases
+ * its path parameter).  Returns true in that case.  Which of the two happens
+ * depends on the ray's own line and sample only. */
 template <int MODE>
 __device__ __forceinline__ bool f_sample_on_line(const tamd_view & v, const OneCtx & ctx,
     double x, double y, double z, double dx, double dy, double dz, RayLine & line, double sl,
@@ -1726,7 +1636,7 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
                 double px = pos[3 * r], py = pos[3 * r + 1], pz = pos[3 * r + 2];
                 const double dx = dir[3 * r], dy = dir[3 * r + 1], dz = dir[3 * r + 2];
                 const int medium0 = index[2 * r];
-                CellCache cell = CELL_CACHE_EMPTY(~0u);
+                CellCache cell = { ~0u, 0u, 0u, -1, nullptr };
                 CellCache * cache = (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr;
                 Sample s;
                 /* fast math: the bracket is a segment of the ray behind q, so the
@@ -1789,16 +1699,8 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
 
 /* ---- the hot kernel ---------------------------------------------------- */
 
-/* Diagnostic builds only (-DTAMD_PROFILE, scripts/exp_lined_profile.sh): what the
- * waves of the lined pass spent their time on.  No product build contains it. */
-#ifdef TAMD_PROFILE
-__device__ ull g_prof[4096][8];
-#define PROF(stmt) do { if (MODEL) { stmt; } } while (0)
-#else
-#define PROF(stmt) do { } while (0)
-#endif
-
 constexpr int kChunk = 64; /* rays a wave draws from the global queue at once */
+constexpr int kTailChunk = 8; /* ... in the last phase of a fast trace: few, and long */
 constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many live lanes */
 constexpr int kCreepUnroll = 4; /* steps per trip of the one-map creep loop */
 
@@ -1834,44 +1736,29 @@ enum { ST_INIT = 0, ST_STEP = 1, ST_BISECT = 2 };
  * resumed after a boundary, or after parking) */
 enum { TRACE_CARRY_MEDIUM = 1 };
 
-/* Launches in passes.  Steps per ray are heavy-tailed (C2: median 163, max
+/* Two-phase launches.  Steps per ray are heavy-tailed (C2: median 163, max
  * 11 327) and a ray's samples are sequential, so a launch lasts as long as its
- * last ray.  A fast trace is therefore cut by ARITHMETIC (run_trace): the first
- * pass takes every ray up to `line_after` steps by the closed form (2.4 us of
- * dependent arithmetic a sample, which four waves per SIMD overlap) and puts a
- * ray that gets there on the `lined` list; when its queue runs dry it hands over
- * what its waves still hold (`parked`).  The last pass (MODEL) takes both lists
- * to the end, a ray beyond `line_after` steps on its line (see RayLine: ~0.2 us a
- * sample in the creep loop), packed into waves again.
+ * longest ray.  Phase A therefore PARKS any ray that reaches `park_after` steps
+ * (its state goes back to the ray arrays, its id to a list) and phase B resumes
+ * the parked rays, packed into few waves that run alone on their SIMDs, with
+ * each ray's line (MODEL; see RayLine) that makes a creeping ray's sample ~7x cheaper.
  * Which arithmetic a sample uses depends only on the ray's own step count and
- * positions, never on scheduling; a ray that changes pass is sampled again where
- * it stands, by the same arithmetic as the sample it was handed over with:
- * results stay deterministic.  (`quantum`: time slices for the closed-form
- * pass -- measured, not used: a slice ends when its slowest wave does, and a
- * sample's latency makes that 0.3 ms per 128 steps however few rays are left.) */
+ * positions, never on scheduling: results stay deterministic. */
 struct PhaseIO {
-        const int * ids;     /* the rays of this pass (NULL: slot == ray, all of them) */
-        const ull * n_dev;   /* ... and their number, on the device */
-        int * parked;        /* where to list the rays that go on in the next closed-form pass */
+        const int * ids;     /* phase B: the parked ray ids (else NULL: slot == ray) */
+        const ull * n_dev;   /* phase B: their number, on the device */
+        int * parked;        /* phase A: where to list parked rays (or NULL) */
         ull * n_parked;
-        int * lined;         /* where to list the rays that reached line_after steps */
-        ull * n_lined;
-        int quantum;         /* steps a ray takes in this pass before it is parked (<= 0: no limit) */
-        int accumulate;      /* 1: length / n_steps continue from the arrays; 2 (a later
-                              * round of a paged geometry): the tentative step too */
+        int park_after;      /* hand a ray over to the next phase at this step count (<= 0: never) */
+        int accumulate;      /* 1 (phase B): length / n_steps continue from the arrays; 2 (a
+                              * later round of a paged geometry): the tentative step too */
         Paging pg;           /* where to list the rays that need a tile paged in (or NULLs) */
-        int drain_lanes;     /* closed-form passes: hand over when the queue is dry and the
-                              * wave is down to this many rays (0: never) */
-        int line_after;      /* the step count from which a ray steps on its line (see
-                              * LINED); <= 0: never (single-pass launches) */
+        int drain_lanes;     /* phase A: hand over when the queue is dry and the wave is down
+                              * to this many rays */
+        int line_after;      /* phases B, C: the step count from which a ray steps on its
+                              * line (see LINED) */
         int chunk;           /* rays a wave draws from the queue at once */
         int creep_lanes;     /* the creep loop engages at or below this many live lanes */
-        int lean;            /* lined pass: samples served by the line and the cached cell take the
-                              * lean way (see LEAN in k_trace); 0: all through f_sample_on_line */
-        int slow_batch, slow_wait; /* ... and the others wait for company (see `slow` in k_trace) */
-        int creep_wait;      /* groups of steps a stopped lane waits for company in the creep loop */
-        const int * ids2;    /* a second list, taken after `ids` (or NULL) */
-        const ull * n_dev2;
 };
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
@@ -1880,11 +1767,13 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
     int flags, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
 {
-        const long n_first = (ph.n_dev != nullptr) ? (long)*ph.n_dev : n; /* of the list `ids` */
-        if (ph.n_dev != nullptr) n = n_first + ((ph.n_dev2 != nullptr) ? (long)*ph.n_dev2 : 0);
-        /* MODEL: besides its accumulated position B (bx, by, bz: the reference's
-         * roundings, in every phase: see kLineTau0) a ray on its line carries
-         * line.s, the path length from the point where the line was laid to B */
+        if (ph.n_dev != nullptr) n = (long)*ph.n_dev;
+        /* MODEL: the position is kept as a path length on the ray's line, B = O +
+         * d * line.s with O (in bx, by, bz) the point where the line was laid,
+         * instead of being accumulated step by step [ref stepper.c:826-830]: over
+         * the thousands of steps of the rays that reach phase B the accumulated
+         * B drifts off the ray by microns (1e-9 m of rounding per step), and
+         * line and position must agree on where a sample is */
         RayLine line;
         line.valid = false, line.s = 0., line.tau = kLineTau0;
         /* Which arithmetic a sample uses depends on the ray's step count alone:
@@ -1901,38 +1790,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         bool exhausted = false;            /* wave-uniform */
         OneCtx ctx;
         d_load_ctx<MODE, FAST>(v, ctx);
-        CellCache cell = CELL_CACHE_EMPTY((FAST && (MODE != TAMD_MODE_GENERIC)) ? BlockStage::lane_at() : ~0u);
-        /* LEAN (lined rays over one map or one regular stack): the cached cell
-         * DECODED -- its node coordinates as doubles, its four elevations, the origin
-         * of its tile -- so that a sample the line serves inside that cell needs no
-         * load, no conversion between integers and doubles (a quarter of the rate of
-         * the other instructions) and none of the general lookup's cases.  Same
-         * values as f_grid_locate / f_grid_blend / f_stack_elevation produce: for an
-         * interior point (double)(int)hx == trunc(hx), and the clamp of the cell
-         * index does nothing. */
-        constexpr bool LEAN = MODEL && (MODE != TAMD_MODE_GENERIC);
-        constexpr bool LEAN_STACK = (MODE == TAMD_MODE_ONE_STACK);
-        const bool lean_ok = LEAN && (ph.lean != 0) && (!LEAN_STACK || (ctx.stack.regular != 0));
-        const tamd_grid & lg = LEAN_STACK ? ctx.stack.proto : ctx.grid;
-        constexpr double lean_guard = LEAN_STACK ? kSeamGuard : 1e-6;
-        const double lean_mx = (double)(lg.nx - 1) - lean_guard, lean_my = (double)(lg.ny - 1) - lean_guard;
-        unsigned dec_id = ~0u; /* the cell.id the decoded values stand for */
-        double dec_cx = -1., dec_cy = -1., dec_x0 = 0., dec_y0 = 0.;
-        double z00 = 0., z10 = 0., z01 = 0., z11 = 0.;
-        int slow_age = 0; /* wave-uniform: trips since a lane began to wait for the general way */
-/* the four elevations of the cached cell, as f_grid_blend decodes them */
-#define LEAN_DECODE_NODES()                                                                    \
-        do {                                                                                   \
-                if (lg.is_signed) {                                                            \
-                        z00 = (double)(int16_t)(cell.lo & 0xffffu), z10 = (double)((int)cell.lo >> 16); \
-                        z01 = (double)(int16_t)(cell.hi & 0xffffu), z11 = (double)((int)cell.hi >> 16); \
-                } else {                                                                       \
-                        z00 = (double)(cell.lo & 0xffffu), z10 = (double)(cell.lo >> 16);      \
-                        z01 = (double)(cell.hi & 0xffffu), z11 = (double)(cell.hi >> 16);      \
-                }                                                                              \
-                z00 = __builtin_fma(z00, lg.dz, lg.z0), z10 = __builtin_fma(z10, lg.dz, lg.z0); \
-                z01 = __builtin_fma(z01, lg.dz, lg.z0), z11 = __builtin_fma(z11, lg.dz, lg.z0); \
-        } while (0)
+        CellCache cell = { ~0u, 0u, 0u, -1, nullptr };
 
         long ray = -1;
         bool dead = false;
@@ -1942,10 +1800,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         int m = -1, k = -1, bm = -1, bk = -1, halvings = 0;
         int home = -1; /* CAN_FAULT: the tile of the ray's last sample (see Sample.slot) */
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_capped = 0;
-#ifdef TAMD_PROFILE
-        ull p_t0 = __builtin_amdgcn_s_memtime(), p_creep = 0, p_slow = 0;
-        unsigned p_iters = 0, p_groups = 0, p_slows = 0, p_fetches = 0, p_lanes = 0, p_entries = 0;
-#endif
 
         for (;;) {
                 /* ---- refill idle lanes from the queue ---- */
@@ -1976,7 +1830,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                         if (need && (rank < avail)) {
                                 ray = pool_next + rank;
-                                if (ph.ids != nullptr) ray = (ray < n_first) ? ph.ids[ray] : ph.ids2[ray - n_first];
+                                if (ph.ids != nullptr) ray = ph.ids[ray];
                                 if (MODEL) line.valid = false, line.s = 0., line.tau = kLineTau0;
                                 bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
                                 dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
@@ -2010,7 +1864,8 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                  * having committed that step.  It calls the same functions on
                  * the same values as the general path, so results do not depend
                  * on whether it engaged. */
-                if (MODEL && !(LEAN && lean_ok) && /* -> the lean loop below */
+                if (MODEL && (MODE != TAMD_MODE_ONE_MAP) &&
+                    !((MODE == TAMD_MODE_ONE_STACK) && ctx.stack.regular) && /* -> the lean loop below */
                     (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
                         for (int it = 0; it < 4096; it++) {
                                 bool fail = false;
@@ -2046,52 +1901,55 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         }
                 }
 
-                /* ---- LEAN: the decoded cell follows the cached one ---- */
-                if (LEAN && lean_ok) {
-                        const bool moved = (cell.id != dec_id);
-                        if (__ballot(moved) != 0) {
-                                if (moved) { /* the general lookup moved the cache */
-                                        dec_id = cell.id;
-                                        const bool cached = (cell.id != ~0u);
-                                        const unsigned slot = LEAN_STACK ? (cell.id >> 24) : 0u;
-                                        const unsigned cell_index = LEAN_STACK ? (cell.id & 0xffffffu) : cell.id;
-                                        const unsigned tile_y = LEAN_STACK ? slot / (unsigned)ctx.stack.nlon : 0u;
-                                        const unsigned tile_x = LEAN_STACK ? slot - tile_y * (unsigned)ctx.stack.nlon : 0u;
-                                        /* the tile's origin as f_stack_elevation computes it */
-                                        dec_x0 = LEAN_STACK ? ctx.stack.lon0 + (int)tile_x * ctx.stack.dlon : lg.x0;
-                                        dec_y0 = LEAN_STACK ? ctx.stack.lat0 + (int)tile_y * ctx.stack.dlat : lg.y0;
-                                        const unsigned cell_iy = cached ? cell_index / (unsigned)lg.nx : 0u;
-                                        dec_cy = cached ? (double)cell_iy : -1.;
-                                        dec_cx = cached ? (double)(cell_index - cell_iy * (unsigned)lg.nx) : -1.;
-                                        LEAN_DECODE_NODES();
-                                }
+                /* The single-map case gets a leaner body still: only the line and
+                 * the cached cell (no closed form, no fetch inside; a lane that
+                 * needs either leaves for one general iteration).  What a launch
+                 * waits for in the end is ONE ray -- C2's longest takes 11 326 steps,
+                 * most of them here, alone in its wave -- so what counts is the
+                 * latency of a trip, and a good part of that is the wave-wide
+                 * question "does any lane have to leave?" (compare, ballot, branch:
+                 * the vector and scalar units wait for each other).  It is asked once
+                 * per kCreepUnroll steps: a lane that cannot take one of them takes
+                 * none of the following either (nothing is committed from there on),
+                 * and the wave leaves after the group. */
+                if (MODEL &&
+                    ((MODE == TAMD_MODE_ONE_MAP) || ((MODE == TAMD_MODE_ONE_STACK) && ctx.stack.regular)) &&
+                    (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
+                        /* one map: the grid.  A regular stack: the tile the cached cell is
+                         * in -- the shared tile shape at that tile's origin, computed as
+                         * f_stack_elevation computes it; a point `interior` to it (same
+                         * guard as there) gets that tile from the directory too */
+                        constexpr bool STACK = (MODE == TAMD_MODE_ONE_STACK);
+                        const tamd_grid & g = STACK ? ctx.stack.proto : ctx.grid;
+                        constexpr double guard = STACK ? kSeamGuard : 1e-6;
+                        const double mx = (double)(g.nx - 1) - guard, my = (double)(g.ny - 1) - guard;
+                        const bool cached = (cell.id != ~0u);
+                        const unsigned slot = STACK ? (cell.id >> 24) : 0u;
+                        const unsigned cell_index = STACK ? (cell.id & 0xffffffu) : cell.id;
+                        const unsigned tile_y = STACK ? slot / (unsigned)ctx.stack.nlon : 0u;
+                        const unsigned tile_x = STACK ? slot - tile_y * (unsigned)ctx.stack.nlon : 0u;
+                        const double x0 = STACK ? ctx.stack.lon0 + (int)tile_x * ctx.stack.dlon : g.x0;
+                        const double y0 = STACK ? ctx.stack.lat0 + (int)tile_y * ctx.stack.dlat : g.y0;
+                        /* The cached cell, decoded once per entry: its node coordinates
+                         * as doubles and its four elevations -- a trip then needs no
+                         * conversion between integers and doubles (a quarter of the
+                         * rate of the other instructions, and on the chain).  Same
+                         * values as f_grid_locate / f_grid_blend produce: for an
+                         * interior point (double)(int)hx == trunc(hx), and the clamp of
+                         * the cell index does nothing. */
+                        const unsigned cell_iy = cached ? cell_index / (unsigned)g.nx : 0u;
+                        const double cy = cached ? (double)cell_iy : -1.;
+                        const double cx = cached ? (double)(cell_index - cell_iy * (unsigned)g.nx) : -1.;
+                        double z00, z10, z01, z11;
+                        if (g.is_signed) {
+                                z00 = (double)(int16_t)(cell.lo & 0xffffu), z10 = (double)((int)cell.lo >> 16);
+                                z01 = (double)(int16_t)(cell.hi & 0xffffu), z11 = (double)((int)cell.hi >> 16);
+                        } else {
+                                z00 = (double)(cell.lo & 0xffffu), z10 = (double)(cell.lo >> 16);
+                                z01 = (double)(cell.hi & 0xffffu), z11 = (double)(cell.hi >> 16);
                         }
-                }
-
-                /* ---- creep loop, lean form ---------------------------------------
-                 * A lined ray inside its decoded cell needs no state machine, no load
-                 * and no question asked to take a step.  This loop steps every lane
-                 * that can, in groups of kCreepUnroll steps (a lane that cannot take
-                 * one of them takes none of the following: nothing is committed from
-                 * there on), and asks the wave-wide question "who has stopped?"
-                 * (compare, ballot, branch: the vector and scalar units wait for each
-                 * other) once per group.  Lanes that stop -- another cell, a
-                 * bisection, a new line, no line yet -- need the general iteration
-                 * below, whose gathers and closed forms cost the wave thousands of
-                 * cycles whoever takes part: they WAIT for company.  The loop goes on
-                 * for the others until a quarter of the wave has stopped, or the first
-                 * to stop has waited ph.creep_wait groups; a wave down to a few rays
-                 * (ph.creep_lanes: what a launch ends with) serves a stopped lane at
-                 * once.  Same functions on the same values as the general iteration:
-                 * when a lane is served changes nothing of what it computes. */
-                if (LEAN && lean_ok) {
-                        PROF(p_creep -= __builtin_amdgcn_s_memtime(); p_entries++);
-                        const tamd_grid & g = lg;
-                        constexpr double guard = lean_guard;
-                        const double mx = lean_mx, my = lean_my;
-                        const double x0 = dec_x0, y0 = dec_y0, cx = dec_cx, cy = dec_cy;
-                        const int n_live = __popcll(__ballot(ray >= 0));
-                        int waited = 0;
+                        z00 = __builtin_fma(z00, g.dz, g.z0), z10 = __builtin_fma(z10, g.dz, g.z0);
+                        z01 = __builtin_fma(z01, g.dz, g.z0), z11 = __builtin_fma(z11, g.dz, g.z0);
                         for (int it = 0; it < 4096; it++) {
                                 /* no short-circuits below: every lane computes
                                  * everything (garbage is harmless, nothing is
@@ -2124,9 +1982,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                          * cases are |alt - elevation| */
                                         double ds_next = clearance * v.slope;
                                         if (ds_next < v.resolution) ds_next = v.resolution;
-                                        /* B += d * ds, as the general iteration does it (a
-                                         * select, not d * 0: the direction of a lane that is
-                                         * not going may be anything, NaN included) */
                                         bx = going ? bx + dx * ds : bx, by = going ? by + dy * ds : by;
                                         bz = going ? bz + dz * ds : bz;
                                         line.tau = going ? line.tau + kLineDrift : line.tau;
@@ -2136,15 +1991,8 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         my_samples += going ? 1 : 0;
                                         ds = going ? ds_next : ds;
                                 }
-                                PROF(p_groups++);
-                                const int n_going = __popcll(__ballot(going));
-                                if (n_going == n_live) continue;
-                                waited++;
-                                if ((n_going == 0) | (n_live <= ph.creep_lanes) | (waited > ph.creep_wait) |
-                                    (4 * (n_live - n_going) >= n_live))
-                                        break;
+                                if (__ballot((ray >= 0) & !going) != 0) break;
                         }
-                        PROF(p_creep += __builtin_amdgcn_s_memtime());
                 }
 
                 /* `drain`: once the queue is dry a wave of phase A hands its rays over
@@ -2152,98 +2000,31 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                  * to their 512th step with most lanes idle -- measured: the queue of
                  * C2 is dry after 2.4 ms and the last wave left at 4.5 ms.  Phase B
                  * packs them again, and has the time: it waits for its longest ray. */
-                const bool drain = !MODEL && (ph.parked != nullptr) && exhausted && (ray >= 0) &&
+                const bool drain = !MODEL && (ph.park_after > 0) && exhausted && (ray >= 0) &&
                     (state == ST_STEP) && (__popcll(__ballot(ray >= 0)) <= ph.drain_lanes);
-                bool park = drain, park_lined = false;
+                bool park = drain;
                 TileFault fault = { -1, 0, 0 }; /* the tiles to page in, if any */
                 double fx = 0, fy = 0, fz = 0; /* where the ray goes back to, then */
-                /* ---- one sample at q = B + d * t ---- */
-                double t = 0.;
-                if (state == ST_STEP) t = ds;
-                if (state == ST_BISECT) t = 0.5 * (ds0 + ds1);
-                Sample s;
-                bool sampled = false; /* LEAN: the sample is in `s` already */
-                if (LEAN && lean_ok) {
-                        /* every lane computes everything (garbage is harmless: the
-                         * flags decide what is used), as in the creep loop */
-                        const bool can = (ray >= 0) & lined_ & line.valid & (state != ST_INIT);
-                        const double sl = line.s + t;
-                        double lat, lon, alt;
-                        f_line_eval(line, sl, lat, lon, alt);
-                        const double hx = (lon - dec_x0) * lg.inv_dx;
-                        const double hy = (lat - dec_y0) * lg.inv_dy;
-                        const bool interior =
-                            (hx > lean_guard) & (hx < lean_mx) & (hy > lean_guard) & (hy < lean_my);
-                        const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);
-                        const bool here = can & (fabs(sl) <= kLineRange) & interior & (dec_cx >= 0.);
-                        /* another cell of the same tile: its nodes, now (the wave waits:
-                         * lanes come here in company, see the creep loop) */
-                        const bool fetch = here & !((tx == dec_cx) & (ty == dec_cy));
-                        if (__ballot(fetch) != 0) {
-                                PROF(p_fetches++);
-                                if (fetch) {
-                                        const unsigned slot = LEAN_STACK ? (cell.id >> 24) : 0u;
-                                        const uint16_t * nodes = LEAN_STACK ? ctx.slots[slot] : lg.nodes;
-                                        const int ix = (int)tx, iy = (int)ty;
-                                        d_cell_get(nodes, lg.nbx, ix, iy, slot << 24, cell, cell.lo, cell.hi);
-                                        cell.id = (slot << 24) | ((unsigned)iy * (unsigned)lg.nx + (unsigned)ix);
-                                        dec_id = cell.id, dec_cx = tx, dec_cy = ty;
-                                        LEAN_DECODE_NODES();
-                                }
-                        }
-                        const double fx_ = hx - tx, fy_ = hy - ty;
-                        const double gx = 1. - fx_, gy = 1. - fy_;
-                        const double elevation =
-                            (z00 * gx * gy + z01 * gx * fy_ + z10 * fx_ * gy + z11 * fx_ * fy_) + ctx.offset;
-                        const double clearance = fabs(alt - elevation);
-                        sampled = here & f_line_serves(line, sl, clearance);
-                        if (sampled) {
-                                s.lat = lat, s.lon = lon, s.alt = alt;
-                                s.fault.centre = -1, s.slot = -1, s.k = 0;
-                                const bool below = (elevation >= alt); /* as d_classify */
-                                s.m = below ? 0 : 1;
-                                s.e0 = below ? -DBL_MAX : elevation;
-                                s.e1 = below ? elevation : DBL_MAX;
+                if ((ray >= 0) && !drain) {
+                        /* ---- one sample at q = B + d * t ---- */
+                        double t = 0.;
+                        if (state == ST_STEP) t = ds;
+                        if (state == ST_BISECT) t = 0.5 * (ds0 + ds1);
+                        double qx = bx, qy = by, qz = bz;
+                        if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
+                                qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
+
+                        Sample s;
+                        if (LINED) {
+                                /* B's parameter: -t on a new line (its origin is q),
+                                 * and a STEP sample then moves B to q */
+                                if (f_sample_on_line<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line,
+                                        line.s + t, s, (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr))
+                                        line.s = -t;
                                 if (state == ST_STEP) line.s += t;
-                        }
-                }
-                /* The other samples go the general way (f_sample_on_line / d_sample).
-                 * On a lined ray that is a closed form plus a new line for the lane
-                 * -- 2.4 us of dependent arithmetic -- during which the rest of the wave
-                 * does nothing.  ph.slow_batch > 1: a lane that needs one waits (it takes
-                 * no sample on this trip) until that many lanes do, or it has waited
-                 * ph.slow_wait trips, or nobody else is left to work for. */
-                bool slow = (ray >= 0) & !drain & !sampled;
-                if (LEAN && lean_ok && (ph.slow_batch > 1)) {
-                        const ull wants = __ballot(slow);
-                        const int n_wants = __popcll(wants), n_live = __popcll(__ballot(ray >= 0));
-                        slow_age = (wants != 0) ? slow_age + 1 : 0;
-                        const bool now = (n_wants >= ph.slow_batch) | (slow_age > ph.slow_wait) |
-                            (n_wants == n_live) | (n_live <= ph.creep_lanes);
-                        if (!now) slow = false;
-                        if (now) slow_age = 0;
-                }
-                double qx = bx, qy = by, qz = bz;
-                if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
-                        qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
-                PROF(p_iters++; p_lanes += __popcll(__ballot(ray >= 0)));
-                if (__ballot(slow) != 0) {
-                        PROF(p_slows++; p_slow -= __builtin_amdgcn_s_memtime());
-                        if (slow) {
-                                if (LINED) {
-                                        /* B's parameter: -t on a new line (its origin is q),
-                                         * and a STEP sample then moves B to q */
-                                        if (f_sample_on_line<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line,
-                                                line.s + t, s, (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr))
-                                                line.s = -t;
-                                        if (state == ST_STEP) line.s += t;
-                                } else
-                                        d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
-                                            (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr);
-                        }
-                        PROF(p_slow += __builtin_amdgcn_s_memtime());
-                }
-                if ((ray >= 0) && !drain && (sampled | slow)) {
+                        } else
+                                d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
+                                    (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr);
                         my_samples++;
                         if (CAN_FAULT && (s.fault.centre >= 0)) {
                                 /* a tile that is not resident: the ray goes back to
@@ -2312,18 +2093,14 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 const bool capped = accept & (count >= max_steps);
                                 done = capped;
                                 my_capped += capped ? 1 : 0;
-                                /* on to the last pass (always at the same step count: the
-                                 * line a ray lays there is part of its arithmetic), or
-                                 * to the next time slice */
-                                park_lined = !MODEL & accept & !capped & (ph.lined != nullptr) &
-                                    (count >= ph.line_after);
-                                park = !MODEL & accept & !capped & !park_lined & (ph.quantum > 0) &
-                                    (ph.parked != nullptr) & (count - count0 >= ph.quantum);
-                                if (MODEL && accept && !capped && !lined_ && (ph.line_after > 0) &&
+                                /* on to the next phase (always at the same step count:
+                                 * the line a ray lays there is part of its arithmetic) */
+                                park = accept & !capped & (ph.park_after > 0) & (count >= ph.park_after);
+                                if (MODEL && accept && !capped && !park && !lined_ &&
                                     (count >= ph.line_after)) {
-                                        /* from here on the ray steps on its line, laid by a
-                                         * fresh sample of its position -- what a ray handed
-                                         * over at this very step goes through */
+                                        /* phase B: from here on the ray steps on its line,
+                                         * laid by a fresh sample of its position -- what a
+                                         * ray handed over at this very step goes through */
                                         lined_ = true;
                                         line.valid = false, line.s = 0.;
                                         state = ST_INIT;
@@ -2348,32 +2125,24 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 ray = -1;
                         }
                 }
-                /* ---- hand rays over to a later pass (whole wave takes part) ---- */
-                if (!MODEL) {
-                        const ull pmask = __ballot(park), lmask = __ballot(park_lined);
-                        if ((pmask | lmask) != 0) {
-                                /* one atomic per list and wave */
-                                ull base = 0, lbase = 0;
-                                if ((threadIdx.x & 63) == 0) {
-                                        if (pmask != 0) base = atomicAdd(ph.n_parked, (ull)__popcll(pmask));
-                                        if (lmask != 0) lbase = atomicAdd(ph.n_lined, (ull)__popcll(lmask));
-                                }
-                                base = __shfl(base, 0, 64), lbase = __shfl(lbase, 0, 64);
-                                if (park | park_lined) {
-                                        const ull mine = park ? pmask : lmask;
-                                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32),
-                                            __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
-                                        if (park)
-                                                ph.parked[base + rank] = (int)ray;
-                                        else
-                                                ph.lined[lbase + rank] = (int)ray;
-                                        pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
-                                        index[2 * ray] = m, index[2 * ray + 1] = k;
-                                        length[ray] = len;
-                                        n_steps[ray] = count;
-                                        my_steps += (ull)(count - count0);
-                                        ray = -1;
-                                }
+                /* ---- park over-long rays (phase A; whole wave takes part) ---- */
+                const ull pmask = __ballot(park);
+                if (pmask != 0) {
+                        const int leader = __builtin_ctzll(pmask);
+                        ull base = 0;
+                        if ((int)(threadIdx.x & 63) == leader)
+                                base = atomicAdd(ph.n_parked, (ull)__popcll(pmask));
+                        base = __shfl(base, leader, 64);
+                        if (park) {
+                                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pmask >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((unsigned)pmask, 0));
+                                ph.parked[base + rank] = (int)ray;
+                                pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
+                                index[2 * ray] = m, index[2 * ray + 1] = k;
+                                length[ray] = len;
+                                n_steps[ray] = count;
+                                my_steps += (ull)(count - count0);
+                                ray = -1;
                         }
                 }
                 /* ---- list the rays that wait for a tile (whole wave takes part) ---- */
@@ -2398,14 +2167,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                 }
         }
 
-#ifdef TAMD_PROFILE
-        if (MODEL && ((threadIdx.x & 63) == 0)) {
-                const unsigned w = (blockIdx.x * 4 + (threadIdx.x >> 6)) & 4095u;
-                g_prof[w][0] = __builtin_amdgcn_s_memtime() - p_t0, g_prof[w][1] = p_creep, g_prof[w][2] = p_slow;
-                g_prof[w][3] = ((ull)p_iters << 32) | p_groups, g_prof[w][4] = ((ull)p_slows << 32) | p_fetches;
-                g_prof[w][5] = p_lanes, g_prof[w][6] = (ull)count, g_prof[w][7] = p_entries;
-        }
-#endif
         block_tally(stats, my_rays, my_steps, my_samples, my_capped);
 }
 
@@ -2827,10 +2588,10 @@ extern "C" int tamd_k_step(struct tamd_view view, long n, double * pos,
  * with a dependent 4-node gather per sample, so a few waves per SIMD are
  * enough to cover the gather latency; TURTLE_AMD_TRACE_WAVES overrides the
  * default for experiments. */
-static int trace_blocks_per_cu(const void * kernel, size_t lds)
+static int trace_blocks_per_cu(const void * kernel)
 {
         int blocks = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 256, lds) !=
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 256, 0) !=
                 hipSuccess ||
             blocks < 1)
                 blocks = 1;
@@ -2842,14 +2603,6 @@ static int trace_blocks_per_cu(const void * kernel, size_t lds)
         return blocks;
 }
 
-#ifdef TAMD_PROFILE
-extern "C" int tamd_dev_prof_read(unsigned long long * out) /* [4096][8] */
-{
-        HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)));
-        return 0;
-}
-#endif
-
 extern "C" void tamd_dev_math_set(int strict) { g_math_strict = strict ? 1 : 0; }
 extern "C" int tamd_dev_math_get(void) { return g_math_strict; }
 
@@ -2859,9 +2612,7 @@ static int launch_trace_(struct tamd_view view, long n, bool n_on_device, double
     int flags, PhaseIO ph, ull * stats, ull * queue)
 {
         const void * kernel = (const void *)k_trace<MODE, FAST, MODEL, PAGED>;
-        /* the lanes' staged blocks (BlockStage): 128 bytes each, and a word to spare */
-        const size_t lds = (FAST && (MODE != TAMD_MODE_GENERIC)) ? 256 * 128 + 16 : 0;
-        long blocks = (long)g_cus * trace_blocks_per_cu(kernel, lds);
+        long blocks = (long)g_cus * trace_blocks_per_cu(kernel);
         const long useful = (n + 255) / 256;
         if (!n_on_device && (blocks > useful)) blocks = useful;
         if (n_on_device) {
@@ -2880,7 +2631,7 @@ static int launch_trace_(struct tamd_view view, long n, bool n_on_device, double
                 if (blocks > wide) blocks = wide;
         }
         hipLaunchKernelGGL((k_trace<MODE, FAST, MODEL, PAGED>), dim3((unsigned)blocks), dim3(256),
-            lds, g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, ph, stats,
+            0, g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, ph, stats,
             queue);
         LAUNCH_CHECK("k_trace");
         return 0;
@@ -2905,25 +2656,25 @@ static int env_int(const char * name, int fallback)
         return ((env != nullptr) && (*env != 0)) ? atoi(env) : fallback;
 }
 
-/* The step count from which a fast trace takes a ray on its line (0: never: one
- * closed-form pass), the steps per time slice of the closed-form passes, and
- * the rays a wave of such a pass may still hold when it hands over after its
- * queue ran dry.  TURTLE_AMD_* override them for experiments. */
+/* Step counts at which a ray moves on to the next phase of a fast trace (0: no
+ * further phase), and the rays a wave of phase A may still hold when it hands
+ * over after the queue ran dry.  TURTLE_AMD_* override them for experiments. */
 static int park_threshold(void)
 {
         static int value = -1;
         if (value < 0) value = max(0, env_int("TURTLE_AMD_PARK", 512));
         return value;
 }
-static int slice_quantum(void)
+static int park_threshold_2(void)
 {
         static int value = -1;
-        if (value < 0) value = max(0, env_int("TURTLE_AMD_QUANTUM", 128));
+        if (value < 0) value = max(0, env_int("TURTLE_AMD_PARK2", 0));
         return value;
 }
 /* Few in a small batch, where the launch waits for single rays in all-but-empty
- * waves; more in a large one, where the last pass is a matter of throughput.  The
- * loop gives the same bits whenever it engages. */
+ * waves (C2, 1 M rays: 8 lanes 6.85 ms, 32 lanes 7.08, 64 lanes 7.4); more in a large
+ * one, where phase B is a matter of throughput (C2 at 4 M rays: 20.5 -> 19.6 ms with 32;
+ * C3, 10 M: 42.6 -> 41.8).  The loop gives the same bits whenever it engages. */
 static int creep_lanes(long n)
 {
         static int value = -2;
@@ -2941,12 +2692,16 @@ static int drain_lanes(void)
 /* One round of a trace: all the rays (pg.ids == NULL), or the ones the last
  * round listed because they needed a tile (they carry on from the arrays).
  *
- * Fast arithmetic runs in two passes (see PhaseIO): a closed-form pass over
- * everything, and the lined pass over what is left of it.
- *
- * parked: room for 3 n ray ids (the lists); queue: TAMD_TRACE_COUNTERS words,
- * zeroed: [0], [10] the work queues of the two passes, [12] the length of the list
- * of rays handed over when the first one's queue ran dry, [11] of the lined list. */
+ * Fast arithmetic runs in phases, each with fewer and longer rays than the one
+ * before: A steps everything to 512 steps and hands over what is left when its
+ * queue runs dry (C2: 260 k of 1 M rays); B takes those to the end.  A ray
+ * changes phase at fixed step counts, or (below 512 steps) where its arithmetic
+ * does not depend on the phase: see LINED.  A third phase C for the rays beyond
+ * a second threshold (TURTLE_AMD_PARK2; a few to a wave, on an otherwise empty
+ * chip) is wired in but off: measured on C2, every threshold from 544 to 2 048
+ * made the trace slower (8.5-9.5 ms against 7.5 ms) -- what phase B waits for
+ * is not its one longest ray but the medium ones (1 000-2 500 steps) stepping in
+ * waves that are neither full nor down to a handful of rays. */
 template <int MODE>
 static int run_trace(struct tamd_view view, long n, double * pos, const double * dir,
     int max_steps, int * index, double * length, int * n_steps, int flags, int * parked,
@@ -2955,8 +2710,7 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         const bool again = (pg.ids != nullptr);
         if (again) flags |= TRACE_CARRY_MEDIUM;
         const int resume = again ? 2 : 0;
-        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, nullptr, nullptr, 0, resume, pg, 0, 0,
-                kChunk, creep_lanes(n), 0, 1, 0, 0, nullptr, nullptr };
+        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, resume, pg, 0, 0, kChunk, creep_lanes(n) };
         if (g_math_strict || !view.fast_ok)
                 return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
@@ -2965,29 +2719,28 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
             (n_steps == nullptr))
                 return launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
-        int * const list[2] = { parked, parked + n };
-        int * const lined = parked + 2 * n;
-        ull * const n_lined = queue + 11;
-        const int lean = env_int("TURTLE_AMD_LEAN", 1), slow_batch = env_int("TURTLE_AMD_SLOW_BATCH", 1);
-        const int slow_wait = env_int("TURTLE_AMD_SLOW_WAIT", 8), creep_wait = env_int("TURTLE_AMD_CREEP_WAIT", 4);
-        /* pass 0: everything, up to `park` steps, handing over what it holds when its
-         * queue runs dry (at most one ray per lane of the chip) */
-        const PhaseIO a = { pg.ids, pg.n_in, list[0], queue + 12, lined, n_lined, 0, resume, pg,
-                drain_lanes(), park, kChunk, creep_lanes(n), 0, 1, 0, 0, nullptr, nullptr };
-        if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length, n_steps,
-                flags, a, stats, queue))
+        /* lists: parked[0 .. n) from A to B, parked[n .. 2n) from B to C; counters:
+         * queue[0], [1], [3]: the work queues of A, B, C; queue[2], [4]: the lists */
+        int park2 = park_threshold_2();
+        if ((park2 <= park) || (max_steps <= park2)) park2 = 0;
+        const PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, resume, pg, drain_lanes(), 0,
+                kChunk, creep_lanes(n) };
+        if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
+                n_steps, flags, a, stats, queue))
                 return 1;
-        /* the last pass: the rays that reached `park` steps, then the ones handed over
-         * when the queue ran dry -- in that order, so that a wave draws rays of one
-         * kind (the second kind turns into the first at its `park`-th step) */
-        const PhaseIO b = { lined, n_lined, nullptr, nullptr, nullptr, nullptr, 0, 1, pg, 0, park, kChunk,
-                creep_lanes(n), lean, slow_batch, slow_wait, creep_wait, list[0], queue + 12 };
+        const PhaseIO b = { parked, queue + 2, park2 ? parked + n : nullptr, queue + 4, park2, 1, pg,
+                0, park, kChunk, creep_lanes(n) };
+        if (launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
+                n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1))
+                return 1;
+        if (park2 == 0) return 0;
+        const PhaseIO c = { parked + n, queue + 4, nullptr, nullptr, 0, 1, pg, 0, park, kTailChunk, creep_lanes(n) };
         return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
-            n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 10);
+            n_steps, flags | TRACE_CARRY_MEDIUM, c, stats, queue + 3);
 }
 
-/* parked, queue: see run_trace.  pg: the round of a paged geometry (paging.c), all
- * NULL otherwise; the counters in `stats` add up over the rounds of a call. */
+/* queue: five counters (see run_trace); parked: room for 2 n ray ids.  pg: the round of a paged geometry (paging.c), all NULL otherwise; the
+ * counters in `stats` add up over the rounds of a call. */
 extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
     int flags, int * parked, struct tamd_paging pg, unsigned long long * stats,
@@ -2995,7 +2748,7 @@ extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
 {
         if (tamd_dev_init()) return 1;
         if (pg.ids == nullptr) HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
-        HIP_TRY(hipMemsetAsync(queue, 0, TAMD_TRACE_COUNTERS * sizeof(ull), g_stream));
+        HIP_TRY(hipMemsetAsync(queue, 0, 5 * sizeof(ull), g_stream));
         if (n <= 0) return 0;
         const int carry = (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0;
         if (view.mode == TAMD_MODE_ONE_MAP)

@@ -26,22 +26,19 @@ extern "C" {
 /* ------------------------------------------------------------------------ */
 
 /* One DEM grid resident in HBM: 16-bit nodes, native little-endian, in BLOCKS
- * of 8 x 8 nodes = 7 x 7 cells (128 bytes, one cache line; rows south->north
- * inside a block and from block to block, nbx blocks per block row): block (bx,
- * by) holds nodes 7 bx .. 7 bx + 7 by 7 by .. 7 by + 7, sharing its last row and
- * column with its neighbours, so that the 2 x 2 nodes of any cell are in ONE
- * block: node (ix, iy) of cell (cx, cy) is at ((cy / 7) * nbx + cx / 7) * 64 +
- * (iy - 7 (cy / 7)) * 8 + ix - 7 (cx / 7).  A sample reads the 2 x 2 nodes of a
- * cell; in rows of nx nodes those are two lines 2 nx bytes apart, here always
- * one, and the next cells of the ray -- whichever way it heads -- are in it too.
+ * of 8 x 8 nodes (128 bytes, one cache line; rows south->north inside a block
+ * and from block to block, nbx blocks per block row, the grid padded to whole
+ * blocks): node (ix, iy) is at ((iy / 8) * nbx + ix / 8) * 64 + (iy % 8) * 8 +
+ * ix % 8.  A sample reads the 2 x 2 nodes of a cell; in rows of nx nodes those
+ * are two lines 2 nx bytes apart, in blocks one line three times out of four,
+ * and the next cells of the ray -- whichever way it heads -- are in it too.
  * Decoding the file format (byte order, row flip, sign) happens ONCE at upload
  * instead of per node access as the reference's get_z callbacks do [ref
  * src/turtle/map.h:47-49, io/hgt.c:127-131, map.c:41-44]; integers are exact,
  * so parity is unaffected.  z = z0 + v * dz with v read as int16 if is_signed
  * else uint16 (signed codecs use z0 = 0, dz = 1, which reproduces "(int16)v"
  * exactly). */
-#define TAMD_BLOCK_NODES 8
-#define TAMD_BLOCK_CELLS 7
+#define TAMD_BLOCK 8
 /* A map projection [ref src/turtle/projection.h:29-46]; type < 0: geodetic */
 enum tamd_proj_type { TAMD_PROJ_NONE = -1, TAMD_PROJ_LAMBERT = 0, TAMD_PROJ_UTM = 1 };
 
@@ -60,8 +57,7 @@ struct tamd_grid {
         double z0, dz;
         double inv_dx, inv_dy; /* 1/dx, 1/dy: the fast-math kernels multiply */
         int is_signed;
-        int nbx, nby; /* blocks per block row, block rows */
-        int pad2_;
+        int nbx; /* blocks of TAMD_BLOCK x TAMD_BLOCK nodes per block row */
         struct tamd_proj proj; /* x, y of a projected map; the stepper projects
                                 * (latitude, longitude) first [ref stepper.c:243-248] */
 };

@@ -241,12 +241,10 @@ void turtle_map_meta(const struct turtle_map * map, struct turtle_map_info * inf
 
 int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
 {
-        /* HBM layout: overlapping blocks of 8 x 8 nodes = 7 x 7 cells (internal.h) */
-        const size_t nbx = (map->nx > 1) ? ((size_t)map->nx - 2) / TAMD_BLOCK_CELLS + 1 : 1;
-        const size_t nby = (map->ny > 1) ? ((size_t)map->ny - 2) / TAMD_BLOCK_CELLS + 1 : 1;
-        const size_t per_block = TAMD_BLOCK_NODES * TAMD_BLOCK_NODES;
-        /* + one block: the pair load of a row's last node reads two bytes on */
-        const size_t bytes = (nbx * nby + 1) * per_block * sizeof(*map->nodes);
+        /* HBM layout: blocks of TAMD_BLOCK x TAMD_BLOCK nodes (internal.h) */
+        const size_t nbx = ((size_t)map->nx + TAMD_BLOCK - 1) / TAMD_BLOCK;
+        const size_t nby = ((size_t)map->ny + TAMD_BLOCK - 1) / TAMD_BLOCK;
+        const size_t bytes = nbx * nby * TAMD_BLOCK * TAMD_BLOCK * sizeof(*map->nodes);
         if (map->d_nodes == NULL) {
                 if (tamd_dev_malloc(&map->d_nodes, bytes)) return 1;
                 map->d_stale = 1;
@@ -254,22 +252,13 @@ int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
         if (map->d_stale) {
                 uint16_t * blocked = calloc(1, bytes);
                 if (blocked == NULL) return 1;
-                size_t bx, by;
-                int lx, ly;
-                for (by = 0; by < nby; by++) {
-                        for (ly = 0; ly < TAMD_BLOCK_NODES; ly++) {
-                                const size_t iy = by * TAMD_BLOCK_CELLS + ly;
-                                if (iy >= (size_t)map->ny) break;
-                                const uint16_t * row = map->nodes + iy * map->nx;
-                                for (bx = 0; bx < nbx; bx++) {
-                                        uint16_t * to = blocked + (by * nbx + bx) * per_block +
-                                            (size_t)ly * TAMD_BLOCK_NODES;
-                                        for (lx = 0; lx < TAMD_BLOCK_NODES; lx++) {
-                                                const size_t ix = bx * TAMD_BLOCK_CELLS + lx;
-                                                if (ix < (size_t)map->nx) to[lx] = row[ix];
-                                        }
-                                }
-                        }
+                int ix, iy;
+                for (iy = 0; iy < map->ny; iy++) {
+                        const uint16_t * row = map->nodes + (size_t)iy * map->nx;
+                        uint16_t * to = blocked + ((size_t)(iy / TAMD_BLOCK) * nbx) * (TAMD_BLOCK * TAMD_BLOCK) +
+                            (size_t)(iy % TAMD_BLOCK) * TAMD_BLOCK;
+                        for (ix = 0; ix < map->nx; ix++)
+                                to[(size_t)(ix / TAMD_BLOCK) * (TAMD_BLOCK * TAMD_BLOCK) + ix % TAMD_BLOCK] = row[ix];
                 }
                 const int failed = tamd_dev_h2d(map->d_nodes, blocked, bytes);
                 free(blocked);
@@ -286,7 +275,7 @@ int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
                 grid->z0 = map->is_signed ? 0. : map->z0;
                 grid->dz = map->is_signed ? 1. : map->dz;
                 grid->is_signed = map->is_signed;
-                grid->nbx = (int)nbx, grid->nby = (int)nby;
+                grid->nbx = (int)nbx;
                 tamd_projection_desc(&map->projection, &grid->proj);
         }
         return 0;
