@@ -257,8 +257,29 @@ __device__ __forceinline__ double f_atan2(double y, double x)
  * ray alone (its own line and path parameter), never on its wave. */
 constexpr double kLineRange = 4000.; /* m, either side of the origin: hard limit */
 constexpr double kLineTolerance = 2e-10; /* see f_line_serves */
-constexpr double kLineTau0 = 1e-9;
-constexpr double kLineDrift = 1e-9;
+/* A ray's position is ACCUMULATED step by step, B += d * ds with the reference's
+ * roundings [ref stepper.c:824, :862-863], in every phase: each step leaves B
+ * up to half an ulp of 6.4e6 m per coordinate (8e-10 m) off the straight line,
+ * mostly the same way from step to step (a skimming ray adds the same increment
+ * thousands of times: 2.7e-6 m measured over the 11 326 steps of C2's longest
+ * ray) -- and the reference decides on ITS positions.  The line is a function of
+ * the path length alone, so a sample taken from it answers for the ideal point
+ * O + d * s, which is off the reference's by that drift.  That is harmless where
+ * it only sizes the next step, and decisive where the medium is decided within
+ * the drift of the boundary (a ray tangent to the ground: one step more or
+ * less is 1e-2 m of path; with positions kept ON the line, as round 1 had them,
+ * 1 ray of C2's million ended a step early, 1.6e-6 of its path, and the others
+ * were within 2e-7 instead of 5e-9).  So the line keeps count of what its
+ * truncation and the drift since it was laid can amount to (tau: kLineTau0 at
+ * the origin + kLineDrift per accepted step), and a sample whose clearance is
+ * not above it is taken again by the closed form AT THE ACCUMULATED POSITION, as
+ * phase A would -- which lays a new line there, whose drift starts from nothing
+ * (the samples of a bisection all leave from one accumulated position: the line
+ * laid at the first of them that is too close to call serves the others). */
+constexpr double kLineTau0 = 1e-9;  /* m: the truncation allowed near a boundary (2e-10 m) and
+                                     * the rounding of latitude and longitude (8e-10 m on the
+                                     * ground, a third of that in elevation) */
+constexpr double kLineDrift = 1e-9; /* m per step: (3 x (2^-31)^2)^0.5 = 8.1e-10 rounded up */
 
 struct RayLine {
         double s;                /* path parameter of the ray's position B */
@@ -1768,12 +1789,9 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
     int flags, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
 {
         if (ph.n_dev != nullptr) n = (long)*ph.n_dev;
-        /* MODEL: the position is kept as a path length on the ray's line, B = O +
-         * d * line.s with O (in bx, by, bz) the point where the line was laid,
-         * instead of being accumulated step by step [ref stepper.c:826-830]: over
-         * the thousands of steps of the rays that reach phase B the accumulated
-         * B drifts off the ray by microns (1e-9 m of rounding per step), and
-         * line and position must agree on where a sample is */
+        /* MODEL: besides its accumulated position B (bx, by, bz: the reference's
+         * roundings, in every phase: see kLineTau0) a ray on its line carries
+         * line.s, the path length from the point where the line was laid to B */
         RayLine line;
         line.valid = false, line.s = 0., line.tau = kLineTau0;
         /* Which arithmetic a sample uses depends on the ray's step count alone:
