@@ -352,6 +352,35 @@ TURTLE_API enum turtle_return turtle_stepper_step_n(
     double * longitude, double * altitude, double * elevation /* [n][2] */,
     double * step, int * index /* [n][2] */, int flags, int space);
 
+/* Flags of turtle_stepper_scatter_n. */
+enum turtle_amd_scatter_flags {
+        /* Begin a walk: sample the positions first (as turtle_stepper_step_n with
+         * a NULL direction does) and zero length[] and steps[].  Without it the
+         * call continues the walk whose state the arrays hold. */
+        TURTLE_AMD_SCATTER_START = 1
+};
+
+/* A scattering walk: generations first_step .. first_step + n_steps - 1 of
+ *     for every ray still inside the data (index[r][0] >= 0):
+ *         turtle_stepper_step(position[r], direction = isotropic unit vector of
+ *                             Philox(first_ray + r, generation; seed))
+ *         length[r] += the step's length;  steps[r] += 1
+ * i.e. the loop of examples/example-pthread.c:66-99 with a new direction at
+ * every step (turtle_amd_isotropic_n gives the same vectors), each step resumed
+ * from the sample the last one returned (TURTLE_AMD_STEP_RESUME: one sample per
+ * step, as the reference's `last` cache has it [impl stepper.c:708-710]).  The
+ * directions are drawn inside the step kernels and the sums kept there, so a
+ * generation moves 80 bytes of ray state in and 64 out and nothing else.
+ * altitude, elevation and index are the sample state between generations (in /
+ * out; filled by the call itself with TURTLE_AMD_SCATTER_START); a ray that
+ * leaves the data keeps index[r][0] = -1 and takes no further step.
+ * turtle_stepper_trace_stats reports the totals of the call. */
+TURTLE_API enum turtle_return turtle_stepper_scatter_n(
+    struct turtle_stepper * stepper, long n, double * position /* [n][3] */,
+    unsigned long long seed, long first_ray, int first_step, int n_steps,
+    double * altitude, double * elevation /* [n][2] */, int * index /* [n][2] */,
+    double * length, int * steps, int flags, int space);
+
 /* Flags of turtle_stepper_trace_n. */
 enum turtle_amd_trace_flags {
         /* On entry index[r][0] holds the medium the ray is in, as returned by

@@ -622,6 +622,50 @@ def test_scattering_walk_against_oracle(math):
     m.destroy()
 
 
+def test_scatter_n_is_the_step_loop(math, tmp_path):
+    """turtle_stepper_scatter_n (directions drawn and sums kept in the kernels) gives,
+    bit for bit, what the loop over turtle_amd_isotropic_n + turtle_stepper_step_n with
+    TURTLE_AMD_STEP_RESUME gives -- on a map and through a stack with a hole, in one
+    call and in two, with numpy arrays and with torch tensors."""
+    import torch
+    m = B.c1_map()
+    stack = B.mosaic(tmp_path, [(45, 3), (45, 4), (46, 3)], 601)
+    for terrain, box, add in ((m, (T.C1_Y, T.C1_X), "add_map"),
+                              (stack, ((45.0, 47.0), (3.0, 5.0)), "add_stack")):
+        st = TA.Stepper()
+        getattr(st, add)(terrain, 0.0)
+        n, K = 5000, 24
+        lat, lon, _, _ = TA.synth.uniform_rays(n, box[0], box[1], seed=8)
+        pos, di = st.position(lat, lon, 20.0)
+        pos = pos[di == 0]
+        n = pos.shape[0]
+        state = st.step(pos.copy(), None)
+        total, moved = np.zeros(n), np.zeros(n, dtype=np.int32)
+        for k in range(K):
+            inside = state["index"][:, 0] >= 0
+            d = TA.isotropic(n, 4242, k, first_ray=17, device=False)
+            state = st.step(state["position"], d, resume=state)
+            moved += inside
+            total += np.where(inside, state["step"], 0.0)
+        w = st.scatter(pos.copy(), 4242, K, first_ray=17)
+        w2 = st.scatter(pos.copy(), 4242, 10, first_ray=17)
+        w2 = st.scatter(None, 4242, K - 10, first_ray=17, first_step=10, state=w2)
+        wd = st.scatter(torch.as_tensor(pos, device="cuda"), 4242, K, first_ray=17)
+        for got in (w, w2, {k: v.cpu().numpy() for k, v in wd.items()}):
+            assert np.array_equal(got["position"], state["position"])
+            assert np.array_equal(got["index"], state["index"])
+            assert np.array_equal(got["steps"], moved)
+            assert np.array_equal(got["length"], total)
+            inside = state["index"][:, 0] >= 0
+            assert np.array_equal(got["altitude"][inside], state["altitude"][inside])
+        s = st.trace_stats()
+        assert s["steps"] == int(moved.sum())
+        assert (moved < K).any() or add == "add_map"      # some rays left through the hole / the rim
+        st.destroy()
+    m.destroy()
+    stack.destroy()
+
+
 def test_gradient_bit_exact(golden, tmp_path):
     """turtle_map_gradient / turtle_stack_gradient [ref map.c:280-392,
     stack.c:364-388]: +,-,*,/ only, so bit-exact, slip at map.c:353 included."""

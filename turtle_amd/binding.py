@@ -17,6 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HOST, DEVICE = 0, 1
 STEP_RESUME = 1
 TRACE_RESUME = 1
+SCATTER_START = 1
 
 RETURN_NAMES = [
     "SUCCESS", "BAD_ADDRESS", "BAD_EXTENSION", "BAD_FORMAT", "BAD_PROJECTION",
@@ -505,6 +506,29 @@ class Stepper:
             _ptr(out["step"]), _ptr(out["index"]), flags, sp))
         out["position"] = pos
         return out
+
+    def scatter(self, position, seed, n_steps, first_ray=0, first_step=0, state=None):
+        """turtle_stepper_scatter_n: `n_steps` generations of single steps in
+        Philox(first_ray + r, generation; seed) directions, sums kept on the device.
+        `state` = the dict a previous call returned (continues that walk: its
+        arrays are updated in place); None starts one at `position`."""
+        flags = 0
+        if state is None:
+            sp = _space_of(position)
+            pos = _as(position, sp).reshape(-1, 3)
+            n = pos.shape[0]
+            state = dict(position=pos, altitude=_new((n,), sp, like=pos),
+                         elevation=_new((n, 2), sp, like=pos),
+                         index=_new((n, 2), sp, np.int32, like=pos),
+                         length=_new((n,), sp, like=pos), steps=_new((n,), sp, np.int32, like=pos))
+            flags = SCATTER_START
+        sp = _space_of(state["position"])
+        n = state["position"].shape[0]
+        _check(lib().turtle_stepper_scatter_n(
+            self.h, C.c_long(n), _ptr(state["position"]), C.c_ulonglong(seed), C.c_long(first_ray),
+            first_step, n_steps, _ptr(state["altitude"]), _ptr(state["elevation"]),
+            _ptr(state["index"]), _ptr(state["length"]), _ptr(state["steps"]), flags, sp))
+        return state
 
     def trace(self, position, direction, max_steps=100000, want=("length", "n_steps"),
               resume_index=None):

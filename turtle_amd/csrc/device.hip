@@ -1467,6 +1467,51 @@ __device__ __forceinline__ void block_tally(ull * __restrict__ stats, ull a, ull
         }
 }
 
+/* ---- counter-based random directions (scattering harness, config C5) ------
+ * Philox-4x32-10 (Salmon et al., SC'11): counter = (ray id, stream), key =
+ * seed.  One block of four 32-bit words gives two 53-bit uniforms, mapped to
+ * an isotropic unit vector.  Any (ray, stream) pair can be regenerated
+ * anywhere, so shards need no shared RNG state. */
+__device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1)
+{
+        for (int round = 0; round < 10; round++) {
+                const unsigned long long p0 = 0xD2511F53ull * c[0];
+                const unsigned long long p1 = 0xCD9E8D57ull * c[2];
+                const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0;
+                const unsigned n1 = (unsigned)p1;
+                const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+                const unsigned n3 = (unsigned)p0;
+                c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+                k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+        }
+}
+
+/* the isotropic unit vector of (ray id, stream; seed): see k_isotropic */
+__device__ __forceinline__ void d_isotropic(ull id, ull stream, ull seed, double & x, double & y, double & z)
+{
+        unsigned c[4] = { (unsigned)id, (unsigned)(id >> 32), (unsigned)stream, (unsigned)(stream >> 32) };
+        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+        const double scale = 1. / 9007199254740992.; /* 2^-53 */
+        const double u1 = (double)(((ull)(c[0] >> 5) << 26) | (c[1] >> 6)) * scale;
+        const double u2 = (double)(((ull)(c[2] >> 5) << 26) | (c[3] >> 6)) * scale;
+        const double ct = 2. * u1 - 1.;
+        const double st = sqrt(1. - ct * ct);
+        const double phi = 2. * kPi * u2;
+        x = st * cos(phi), y = st * sin(phi), z = ct;
+}
+
+/* Where a batch of single steps takes its directions from: an array, or -- a
+ * scattering walk (turtle_stepper_scatter_n) -- Philox(first + ray, stream; seed)
+ * drawn in the kernel (the 48 bytes a ray's direction costs to write and read
+ * back are a third of what a step moves); and what it adds up per ray. */
+struct StepWalk {
+        int on;
+        ull seed, stream;
+        long first;
+        double * length; /* += the length of the step */
+        int * steps;     /* += 1 */
+};
+
 /* What a batch of single steps defers to its second pass: the rays that
  * crossed a boundary (~2-5 % of them), and the tentative length of each. */
 struct CrossList {
@@ -1490,10 +1535,11 @@ __device__ __forceinline__ void step_items(const tamd_view & v, long n,
     double * __restrict__ pos, const double * __restrict__ dir,
     double * __restrict__ lat, double * __restrict__ lon, double * __restrict__ alt,
     double * __restrict__ elev, double * __restrict__ step, int * __restrict__ index,
-    int flags, CrossList cross, Paging pg, ull * __restrict__ stats)
+    int flags, CrossList cross, Paging pg, ull * __restrict__ stats, StepWalk walk)
 {
         OneCtx ctx;
         d_load_ctx<MODE, FAST>(v, ctx);
+        const bool directed = (dir != nullptr) || walk.on;
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_plain = 0;
         PAGED_ITEMS(pg, n, i0, r) /* whole waves go round: see the listings */
         {
@@ -1501,10 +1547,12 @@ __device__ __forceinline__ void step_items(const tamd_view & v, long n,
                 double listed_ds = 0.;
                 TileFault fault = { -1, 0, 0 }; /* tiles to page in: the ray is left as it is, and listed */
                 int home = -1;
+                /* a walk: a ray that has left the data takes no further step */
+                if (walk.on && (r >= 0) && (index[2 * r] < 0)) r = -1;
                 if (r >= 0) {
                 double px = pos[3 * r], py = pos[3 * r + 1], pz = pos[3 * r + 2];
                 Sample s;
-                if ((flags & TURTLE_AMD_STEP_RESUME) && (dir != nullptr) && (index[2 * r] >= 0)) {
+                if ((flags & TURTLE_AMD_STEP_RESUME) && directed && (index[2 * r] >= 0)) {
                         /* the caller hands back the sample of this position
                          * [ref stepper.c:708-710, :745-748]; its latitude and
                          * longitude are not read: whatever becomes of the step,
@@ -1523,9 +1571,12 @@ __device__ __forceinline__ void step_items(const tamd_view & v, long n,
                 double ds = 0.;
                 if ((s.m >= 0) && (fault.centre < 0)) {
                         ds = d_step_length(v, s.alt, s.e0, s.e1, s.m);
-                        if (dir != nullptr) {
-                                const double dx = dir[3 * r], dy = dir[3 * r + 1],
-                                             dz = dir[3 * r + 2];
+                        if (directed) {
+                                double dx, dy, dz;
+                                if (walk.on)
+                                        d_isotropic((ull)(walk.first + r), walk.stream, walk.seed, dx, dy, dz);
+                                else
+                                        dx = dir[3 * r], dy = dir[3 * r + 1], dz = dir[3 * r + 2];
                                 px += dx * ds, py += dy * ds, pz += dz * ds;
                                 const int medium0 = s.m, data0 = s.k;
                                 Sample s1;
@@ -1567,6 +1618,8 @@ __device__ __forceinline__ void step_items(const tamd_view & v, long n,
                                         px += dx * ds1, py += dy * ds1, pz += dz * ds1;
                                 }
                                 if (fault.centre < 0) pos[3 * r] = px, pos[3 * r + 1] = py, pos[3 * r + 2] = pz;
+                                /* (a listed ray: k_bisect's, with the length it ends up with) */
+                                if (walk.on && !listed && (fault.centre < 0)) walk.length[r] += ds, walk.steps[r] += 1;
                         }
                 }
                 if (fault.centre >= 0) listed = false;
@@ -1616,8 +1669,8 @@ __device__ __forceinline__ void step_items(const tamd_view & v, long n,
         tamd_view v, long n, double * __restrict__ pos, const double * __restrict__ dir,       \
             double * __restrict__ lat, double * __restrict__ lon, double * __restrict__ alt,   \
             double * __restrict__ elev, double * __restrict__ step, int * __restrict__ index,  \
-            int flags, CrossList cross, Paging pg, ull * __restrict__ stats
-#define STEP_PASS v, n, pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats
+            int flags, CrossList cross, Paging pg, ull * __restrict__ stats, StepWalk walk
+#define STEP_PASS v, n, pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats, walk
 template <int MODE, bool FAST>
 __global__ void __launch_bounds__(256) k_step(STEP_ARGS)
 {
@@ -1640,7 +1693,7 @@ template <int MODE, bool FAST>
 __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict__ pos,
     const double * __restrict__ dir, double * __restrict__ lat, double * __restrict__ lon,
     double * __restrict__ alt, double * __restrict__ elev, double * __restrict__ step,
-    int * __restrict__ index, CrossList cross, Paging pg, ull * __restrict__ stats)
+    int * __restrict__ index, CrossList cross, Paging pg, ull * __restrict__ stats, StepWalk walk)
 {
         OneCtx ctx;
         d_load_ctx<MODE, FAST>(v, ctx);
@@ -1655,7 +1708,11 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
                 r = cross.ray[i];
                 double ds = cross.ds[i];
                 double px = pos[3 * r], py = pos[3 * r + 1], pz = pos[3 * r + 2];
-                const double dx = dir[3 * r], dy = dir[3 * r + 1], dz = dir[3 * r + 2];
+                double dx, dy, dz;
+                if (walk.on)
+                        d_isotropic((ull)(walk.first + r), walk.stream, walk.seed, dx, dy, dz);
+                else
+                        dx = dir[3 * r], dy = dir[3 * r + 1], dz = dir[3 * r + 2];
                 const int medium0 = index[2 * r];
                 CellCache cell = { ~0u, 0u, 0u, -1, nullptr };
                 CellCache * cache = (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr;
@@ -1709,6 +1766,7 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
                         elev[2 * r + 1] = (s.m >= 0) ? s.e1 : 0.;
                 }
                 if (step) step[r] = ds;
+                if (walk.on) walk.length[r] += ds, walk.steps[r] += 1;
                 index[2 * r] = s.m, index[2 * r + 1] = s.k;
                 my_rays++;
                 }
@@ -2188,25 +2246,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         block_tally(stats, my_rays, my_steps, my_samples, my_capped);
 }
 
-/* ---- counter-based random directions (scattering harness, config C5) ------
- * Philox-4x32-10 (Salmon et al., SC'11): counter = (ray id, stream), key =
- * seed.  One block of four 32-bit words gives two 53-bit uniforms, mapped to
- * an isotropic unit vector.  Any (ray, stream) pair can be regenerated
- * anywhere, so shards need no shared RNG state. */
-__device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1)
-{
-        for (int round = 0; round < 10; round++) {
-                const unsigned long long p0 = 0xD2511F53ull * c[0];
-                const unsigned long long p1 = 0xCD9E8D57ull * c[2];
-                const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0;
-                const unsigned n1 = (unsigned)p1;
-                const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
-                const unsigned n3 = (unsigned)p0;
-                c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
-                k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
-        }
-}
-
 __global__ void k_philox(long n, ull seed, ull stream, long first, unsigned * __restrict__ out)
 {
         for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
@@ -2223,17 +2262,9 @@ __global__ void k_isotropic(long n, ull seed, ull stream, long first, double * _
 {
         for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
              r += (long)gridDim.x * blockDim.x) {
-                const ull id = (ull)(first + r);
-                unsigned c[4] = { (unsigned)id, (unsigned)(id >> 32), (unsigned)stream,
-                        (unsigned)(stream >> 32) };
-                philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
-                const double scale = 1. / 9007199254740992.; /* 2^-53 */
-                const double u1 = (double)(((ull)(c[0] >> 5) << 26) | (c[1] >> 6)) * scale;
-                const double u2 = (double)(((ull)(c[2] >> 5) << 26) | (c[3] >> 6)) * scale;
-                const double ct = 2. * u1 - 1.;
-                const double st = sqrt(1. - ct * ct);
-                const double phi = 2. * kPi * u2;
-                dir[3 * r] = st * cos(phi), dir[3 * r + 1] = st * sin(phi), dir[3 * r + 2] = ct;
+                double x, y, z;
+                d_isotropic((ull)(first + r), stream, seed, x, y, z);
+                dir[3 * r] = x, dir[3 * r + 1] = y, dir[3 * r + 2] = z;
         }
 }
 
@@ -2553,7 +2584,7 @@ extern "C" int tamd_k_position(struct tamd_view view, long n, const double * lat
  * queue: as for a trace (queue[2 * stride] counts the listed rays), or NULL. */
 static int run_step(struct tamd_view view, long n, double * pos, const double * dir,
     double * lat, double * lon, double * alt, double * elev, double * step, int * index,
-    int flags, CrossList cross, Paging pg, ull * stats)
+    int flags, CrossList cross, Paging pg, ull * stats, StepWalk walk)
 {
         const dim3 grid(grid_for(n, 256)), block(256);
         const bool strict = g_math_strict || !view.fast_ok;
@@ -2561,13 +2592,13 @@ static int run_step(struct tamd_view view, long n, double * pos, const double * 
         do {                                                                                   \
                 if (strict)                                                                    \
                         hipLaunchKernelGGL((k_step<MODE, false>), grid, block, 0, g_stream, view, n,   \
-                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats);      \
+                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats, walk); \
                 else if (MODE == TAMD_MODE_GENERIC)                                            \
                         hipLaunchKernelGGL((k_step<MODE, true>), grid, block, 0, g_stream, view, n,    \
-                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats);      \
+                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats, walk); \
                 else                                                                           \
                         hipLaunchKernelGGL((k_step_fast<MODE>), grid, block, 0, g_stream, view, n,     \
-                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats);      \
+                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats, walk); \
                 LAUNCH_CHECK("k_step");                                                        \
                 if (cross.ray == nullptr) break;                                               \
                 /* the listed rays are a few percent of n, and their number is on the        \
@@ -2575,10 +2606,10 @@ static int run_step(struct tamd_view view, long n, double * pos, const double * 
                 const dim3 few(grid_for(n / 10 + 1, 256));                                     \
                 if (strict)                                                                    \
                         hipLaunchKernelGGL((k_bisect<MODE, false>), few, block, 0, g_stream, view,     \
-                            pos, dir, lat, lon, alt, elev, step, index, cross, pg, stats);     \
+                            pos, dir, lat, lon, alt, elev, step, index, cross, pg, stats, walk); \
                 else                                                                           \
                         hipLaunchKernelGGL((k_bisect<MODE, true>), few, block, 0, g_stream, view,      \
-                            pos, dir, lat, lon, alt, elev, step, index, cross, pg, stats);     \
+                            pos, dir, lat, lon, alt, elev, step, index, cross, pg, stats, walk); \
                 LAUNCH_CHECK("k_bisect");                                                      \
         } while (0)
         if (view.mode == TAMD_MODE_ONE_MAP)
@@ -2598,8 +2629,9 @@ extern "C" int tamd_k_step(struct tamd_view view, long n, double * pos,
         if (tamd_dev_init()) return 1;
         if (n <= 0) return 0;
         const CrossList none = { nullptr, nullptr, nullptr };
+        const StepWalk no_walk = { 0, 0, 0, 0, nullptr, nullptr };
         return run_step(view, n, pos, dir, lat, lon, alt, elev, step, index, flags, none, pg,
-            nullptr);
+            nullptr, no_walk);
 }
 
 /* Waves per SIMD the trace kernel is launched with.  It is fp64-VALU bound
@@ -2791,8 +2823,27 @@ extern "C" int tamd_k_step_dir(struct tamd_view view, long n, double * pos,
         HIP_TRY(hipMemsetAsync(queue, 0, 3 * sizeof(ull), g_stream));
         if (n <= 0) return 0;
         const CrossList cross = { cross_ray, (cross_ray != nullptr) ? cross_ds : nullptr, queue + 2 };
+        const StepWalk no_walk = { 0, 0, 0, 0, nullptr, nullptr };
         return run_step(view, n, pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg,
-            stats);
+            stats, no_walk);
+}
+
+/* One generation of a scattering walk: as tamd_k_step_dir with
+ * TURTLE_AMD_STEP_RESUME, the directions drawn in the kernels from Philox(first +
+ * ray, stream; seed) and the step added to length[] / steps[] */
+extern "C" int tamd_k_step_walk(struct tamd_view view, long n, double * pos, double * alt,
+    double * elev, int * index, unsigned long long seed, unsigned long long stream, long first,
+    double * length, int * steps, int * cross_ray, double * cross_ds, struct tamd_paging pg,
+    unsigned long long * stats, unsigned long long * queue)
+{
+        if (tamd_dev_init()) return 1;
+        /* (stats add up over the generations of a walk: the caller zeroes them) */
+        HIP_TRY(hipMemsetAsync(queue, 0, 3 * sizeof(ull), g_stream));
+        if (n <= 0) return 0;
+        const CrossList cross = { cross_ray, cross_ds, queue + 2 };
+        const StepWalk walk = { 1, seed, stream, first, length, steps };
+        return run_step(view, n, pos, nullptr, nullptr, nullptr, alt, elev, nullptr, index,
+            TURTLE_AMD_STEP_RESUME, cross, pg, stats, walk);
 }
 
 extern "C" int tamd_k_philox(long n, unsigned long long seed, unsigned long long stream,

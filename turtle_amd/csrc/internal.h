@@ -201,6 +201,14 @@ int tamd_k_step_dir(struct tamd_view view, long n, double * pos,
     double * elev, double * step, int * index, int flags, int * cross_ray,
     double * cross_ds, struct tamd_paging pg, unsigned long long * stats,
     unsigned long long * queue);
+/* one generation of turtle_stepper_scatter_n: single steps resumed from the
+ * sample in alt / elev / index, directions drawn in the kernels from Philox(first
+ * + ray, stream; seed), the step added to length[] and steps[]; cross_ray /
+ * cross_ds as for tamd_k_step_dir (not NULL); stats are NOT zeroed */
+int tamd_k_step_walk(struct tamd_view view, long n, double * pos, double * alt,
+    double * elev, int * index, unsigned long long seed, unsigned long long stream, long first,
+    double * length, int * steps, int * cross_ray, double * cross_ds, struct tamd_paging pg,
+    unsigned long long * stats, unsigned long long * queue);
 int tamd_k_philox(long n, unsigned long long seed, unsigned long long stream,
     long first, unsigned * out);
 int tamd_k_isotropic(long n, unsigned long long seed, unsigned long long stream,

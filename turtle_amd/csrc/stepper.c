@@ -637,6 +637,93 @@ static enum turtle_return step_n(struct tamd_error * error, struct turtle_steppe
         return TURTLE_RETURN_SUCCESS;
 }
 
+/* ---- scattering walk ------------------------------------------------------ */
+
+struct walk_args {
+        long n;
+        void *pos, *alt, *elev, *index, *length, *steps;
+        unsigned long long seed, stream;
+        long first;
+};
+
+static int walk_round(struct turtle_stepper * stepper, struct tamd_paging pg, int round, void * p)
+{
+        struct walk_args * a = p;
+        (void)round;
+        return tamd_k_step_walk(stepper->view, a->n, a->pos, a->alt, a->elev, a->index, a->seed,
+            a->stream, a->first, a->length, a->steps, stepper->d_parked, stepper->d_scratch_ds, pg,
+            stepper->d_stats, stepper->d_stats + 4);
+}
+
+static int walk_start_round(struct turtle_stepper * stepper, struct tamd_paging pg, int round, void * p)
+{
+        struct walk_args * a = p;
+        (void)round;
+        return tamd_k_step(stepper->view, a->n, a->pos, NULL, NULL, NULL, a->alt, a->elev, NULL,
+            a->index, 0, pg);
+}
+
+enum turtle_return turtle_stepper_scatter_n(struct turtle_stepper * stepper, long n,
+    double * position, unsigned long long seed, long first_ray, int first_step, int n_steps,
+    double * altitude, double * elevation, int * index, double * length, int * steps, int flags,
+    int space)
+{
+        TAMD_ERROR_INIT(&turtle_stepper_scatter_n);
+        if ((position == NULL) || (altitude == NULL) || (elevation == NULL) || (index == NULL) ||
+            (length == NULL) || (steps == NULL))
+                return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
+        if ((n_steps < 0) || (first_step < 0))
+                return TAMD_RAISE(TURTLE_RETURN_DOMAIN_ERROR, "invalid input parameter(s)");
+        if (n <= 0) return TURTLE_RETURN_SUCCESS;
+        if (tamd_stepper_scratch(stepper, n) != 0) {
+                if (stepper->parked_capacity < 0) return TAMD_RAISE_DEVICE();
+                return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR, "batch too large");
+        }
+        struct tamd_stage st;
+        struct walk_args a = { n, NULL, NULL, NULL, NULL, NULL, NULL, seed, 0, first_ray };
+        const size_t nb = (size_t)n * sizeof(double);
+        const int start = (flags & TURTLE_AMD_SCATTER_START) != 0;
+        int bad = tamd_stage_begin(&st, space, 7 * nb + 3 * n * sizeof(int)) ||
+            tamd_stage_in(&st, position, 3 * nb, &a.pos);
+        if (!bad && start)
+                bad = tamd_stage_out(&st, altitude, nb, &a.alt) ||
+                    tamd_stage_out(&st, elevation, 2 * nb, &a.elev) ||
+                    tamd_stage_out(&st, index, 2 * n * sizeof(int), &a.index) ||
+                    tamd_stage_out(&st, length, nb, &a.length) ||
+                    tamd_stage_out(&st, steps, n * sizeof(int), &a.steps);
+        else if (!bad)
+                bad = tamd_stage_in(&st, altitude, nb, &a.alt) ||
+                    tamd_stage_in(&st, elevation, 2 * nb, &a.elev) ||
+                    tamd_stage_in(&st, index, 2 * n * sizeof(int), &a.index) ||
+                    tamd_stage_in(&st, length, nb, &a.length) ||
+                    tamd_stage_in(&st, steps, n * sizeof(int), &a.steps);
+        if (bad) return TAMD_RAISE_DEVICE();
+        char message[4200];
+        int rc = 0, k;
+        if (start) {
+                rc = stepper_rounds(stepper, n, &walk_start_round, &a, message, sizeof(message));
+                if ((rc == 0) && (tamd_dev_zero(a.length, nb) || tamd_dev_zero(a.steps, n * sizeof(int)) ||
+                        tamd_dev_zero(stepper->d_stats, 4 * sizeof(*stepper->d_stats))))
+                        rc = TURTLE_RETURN_LIBRARY_ERROR;
+        } else if (stepper->d_stats == NULL) {
+                rc = tamd_stepper_flatten(stepper, message, sizeof(message));
+                if (rc < 0) rc = TURTLE_RETURN_LIBRARY_ERROR;
+        }
+        for (k = 0; (rc == 0) && (k < n_steps); k++) {
+                a.stream = (unsigned long long)(first_step + k);
+                rc = stepper_rounds(stepper, n, &walk_round, &a, message, sizeof(message));
+        }
+        if (rc == TURTLE_RETURN_LIBRARY_ERROR) return TAMD_RAISE_DEVICE();
+        if (rc != 0) return TAMD_RAISE((enum turtle_return)rc, "%s", message);
+        if (tamd_stage_fetch(&st, position, 3 * nb, a.pos) || tamd_stage_fetch(&st, altitude, nb, a.alt) ||
+            tamd_stage_fetch(&st, elevation, 2 * nb, a.elev) ||
+            tamd_stage_fetch(&st, index, 2 * n * sizeof(int), a.index) ||
+            tamd_stage_fetch(&st, length, nb, a.length) ||
+            tamd_stage_fetch(&st, steps, n * sizeof(int), a.steps) || tamd_stage_end(&st))
+                return TAMD_RAISE_DEVICE();
+        return TURTLE_RETURN_SUCCESS;
+}
+
 enum turtle_return turtle_stepper_step_n(struct turtle_stepper * stepper, long n,
     double * position, const double * direction, double * latitude, double * longitude,
     double * altitude, double * elevation, double * step, int * index, int flags,
