@@ -379,6 +379,8 @@ def run_workload(name, args, env, headline):
         if not args.no_cpu and world == 1:
             cores = host_cores()
             m = min(n, PARITY_RAYS if not headline else args.cpu_rays)
+            if scatter:
+                m = min(m, 2 * PARITY_RAYS)      # a scalar CPU walk: 2.4e6 steps/s
             p_host, d_host = pos0[:m].cpu().numpy(), direction[:m].cpu().numpy()
             if scatter:
                 w = walk_state["w"]

@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+try:
+    # A process that uses both PyTorch and libturtle_amd must load torch FIRST: the
+    # wheel brings its own HIP runtime, and the one the library would otherwise pull
+    # in from /opt/rocm leaves torch.cuda without a device
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
