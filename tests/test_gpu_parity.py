@@ -623,13 +623,17 @@ def test_scattering_walk_against_oracle(math):
 
 
 def test_scatter_n_is_the_step_loop(math, tmp_path):
-    """turtle_stepper_scatter_n (directions drawn and sums kept in the kernels) gives,
-    bit for bit, what the loop over turtle_amd_isotropic_n + turtle_stepper_step_n with
-    TURTLE_AMD_STEP_RESUME gives -- on a map and through a stack with a hole, in one
-    call and in two, with numpy arrays and with torch tensors."""
+    """turtle_stepper_scatter_n (a ray's whole walk in one kernel, directions drawn and
+    sums kept there) against the loop over turtle_amd_isotropic_n +
+    turtle_stepper_step_n with TURTLE_AMD_STEP_RESUME: bit for bit in strict
+    arithmetic; in fast arithmetic the loop bisects a crossing on the ray's line and
+    the walk by the closed form (1e-9 m apart: a ray that lands on the other side of a
+    surface by that much diverges, and is counted).  On a map and through a stack with
+    a hole (whose tiles come in while the first walk runs: that one goes generation
+    by generation, in rounds); in one call and in two; numpy arrays and torch tensors."""
     import torch
     m = B.c1_map()
-    stack = B.mosaic(tmp_path, [(45, 3), (45, 4), (46, 3)], 601)
+    stack = B.mosaic(tmp_path, [(45, 3), (45, 4), (46, 3)], 1201)
     for terrain, box, add in ((m, (T.C1_Y, T.C1_X), "add_map"),
                               (stack, ((45.0, 47.0), (3.0, 5.0)), "add_stack")):
         st = TA.Stepper()
@@ -648,19 +652,26 @@ def test_scatter_n_is_the_step_loop(math, tmp_path):
             moved += inside
             total += np.where(inside, state["step"], 0.0)
         w = st.scatter(pos.copy(), 4242, K, first_ray=17)
+        s = st.trace_stats()
+        assert s["steps"] == int(w["steps"].sum())
+        if math == "strict":
+            assert np.array_equal(w["position"], state["position"])
+            assert np.array_equal(w["index"], state["index"])
+            assert np.array_equal(w["steps"], moved) and np.array_equal(w["length"], total)
+            inside = state["index"][:, 0] >= 0
+            assert np.array_equal(w["altitude"][inside], state["altitude"][inside])
+        else:
+            same = (w["index"][:, 0] == state["index"][:, 0]) & (w["steps"] == moved)
+            assert (~same).sum() <= 3, int((~same).sum())
+            assert np.abs(w["position"][same] - state["position"][same]).max() < 1e-6
+            assert np.abs(w["length"][same] - total[same]).max() < 1e-6
         w2 = st.scatter(pos.copy(), 4242, 10, first_ray=17)
         w2 = st.scatter(None, 4242, K - 10, first_ray=17, first_step=10, state=w2)
         wd = st.scatter(torch.as_tensor(pos, device="cuda"), 4242, K, first_ray=17)
-        for got in (w, w2, {k: v.cpu().numpy() for k, v in wd.items()}):
-            assert np.array_equal(got["position"], state["position"])
-            assert np.array_equal(got["index"], state["index"])
-            assert np.array_equal(got["steps"], moved)
-            assert np.array_equal(got["length"], total)
-            inside = state["index"][:, 0] >= 0
-            assert np.array_equal(got["altitude"][inside], state["altitude"][inside])
-        s = st.trace_stats()
-        assert s["steps"] == int(moved.sum())
-        assert (moved < K).any() or add == "add_map"      # some rays left through the hole / the rim
+        for got in (w2, {k: v.cpu().numpy() for k, v in wd.items()}):
+            for key in ("position", "index", "steps", "length"):
+                assert np.array_equal(got[key], w[key]), key
+        assert (w["steps"] < K).any() or add == "add_map"   # some rays left through the hole / the rim
         st.destroy()
     m.destroy()
     stack.destroy()

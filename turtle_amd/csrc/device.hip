@@ -2246,6 +2246,154 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         block_tally(stats, my_rays, my_steps, my_samples, my_capped);
 }
 
+/* ---- a whole scattering walk per ray ----------------------------------------
+ *
+ * turtle_stepper_scatter_n over a geometry with every tile resident: each lane
+ * takes a ray through ALL its generations, the ray's state in registers from
+ * its first step to its last -- where the generation-by-generation form
+ * (k_step + k_bisect per generation) streams 136 bytes of it out and in again
+ * at every step, which is what bounds that form.  Same state
+ * machine as k_trace, one sample per live lane and trip whatever the lane is
+ * doing (stepping, or bisecting a crossing: lanes need not be at the same
+ * generation), with two differences: an accepted step ends a generation (a new
+ * direction from Philox(first + ray, generation; seed)), and a located crossing
+ * does not end the ray but moves it into the medium it entered, from the last
+ * sample the bisection took there [ref stepper.c:849-858: that sample is what
+ * turtle_stepper_step publishes and caches for the next call].  Same arithmetic
+ * on the same values as the generation-by-generation form: same bits.
+ * Persistent waves, rays from a queue (wave-aggregated draws), as in k_trace. */
+struct WalkIO {
+        ull seed;
+        long first;      /* the global index of ray 0 */
+        int first_step;  /* the generation of the first step */
+        int n_steps;     /* generations to take */
+};
+
+template <int MODE, bool FAST>
+__global__ void __launch_bounds__(256) k_walk(tamd_view v, long n, double * __restrict__ pos,
+    double * __restrict__ alt, double * __restrict__ elev, int * __restrict__ index,
+    double * __restrict__ length, int * __restrict__ steps, WalkIO io, ull * __restrict__ stats,
+    ull * __restrict__ queue)
+{
+        long pool_next = 0, pool_end = 0; /* wave-uniform */
+        bool exhausted = false;            /* wave-uniform */
+        OneCtx ctx;
+        d_load_ctx<MODE, FAST>(v, ctx);
+        CellCache cell = { ~0u, 0u, 0u, -1, nullptr };
+        CellCache * cache = (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr;
+
+        long ray = -1;
+        bool dead = false;
+        int state = ST_STEP, count = 0;
+        double bx = 0, by = 0, bz = 0, dx = 0, dy = 0, dz = 0, len = 0;
+        double ds = 0, ds0 = 0, ds1 = 0;
+        double s_alt = 0, s_e0 = 0, s_e1 = 0; /* the sample the ray stands on */
+        double b_alt = 0, b_e0 = 0, b_e1 = 0; /* the bisection's last sample of the new medium */
+        int m = -1, k = -1, bm = -1, bk = -1, halvings = 0;
+        ull my_rays = 0, my_steps = 0, my_samples = 0, my_plain = 0;
+
+        for (;;) {
+                /* ---- refill idle lanes from the queue (as k_trace) ---- */
+                for (;;) {
+                        const bool need = (ray < 0) && !dead;
+                        const ull mask = __ballot(need);
+                        if (mask == 0) break;
+                        if (pool_next >= pool_end) {
+                                if (exhausted) {
+                                        if (need) dead = true;
+                                        break;
+                                }
+                                ull base = 0;
+                                if ((threadIdx.x & 63) == 0) base = atomicAdd(queue, (ull)kChunk);
+                                base = __shfl(base, 0, 64);
+                                pool_next = (long)base;
+                                pool_end = min((long)base + kChunk, n);
+                                if ((long)base >= n) {
+                                        exhausted = true;
+                                        pool_next = pool_end = 0;
+                                }
+                                continue;
+                        }
+                        const long avail = pool_end - pool_next;
+                        const int rank = __builtin_amdgcn_mbcnt_hi(
+                            (unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        if (need && (rank < avail)) {
+                                ray = pool_next + rank;
+                                m = index[2 * ray], k = index[2 * ray + 1];
+                                if ((m < 0) || (io.n_steps <= 0)) {
+                                        ray = -1; /* has left the data: no further step */
+                                } else {
+                                        bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
+                                        s_alt = alt[ray], s_e0 = elev[2 * ray], s_e1 = elev[2 * ray + 1];
+                                        len = 0., count = 0, state = ST_STEP;
+                                        ds = d_step_length(v, s_alt, s_e0, s_e1, m);
+                                        d_isotropic((ull)(io.first + ray), (ull)io.first_step, io.seed, dx, dy, dz);
+                                }
+                        }
+                        pool_next += min((long)__popcll(mask), avail);
+                }
+                if (__ballot(ray >= 0) == 0) {
+                        if (exhausted) break;
+                        continue; /* (every ray drawn had left the data: draw again) */
+                }
+                if (ray >= 0) {
+                        /* ---- one sample at q = B + d * t ---- */
+                        const double t = (state == ST_STEP) ? ds : 0.5 * (ds0 + ds1);
+                        const double qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
+                        Sample s;
+                        d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s, cache);
+                        my_samples++;
+                        /* ---- bookkeeping: STEP and BISECT together, as selects (k_trace) ---- */
+                        const bool stepping = (state == ST_STEP);
+                        const bool same = (s.m == m);
+                        const bool accept = stepping & same;
+                        const bool cross = stepping & !same;
+                        const bool other = !same;
+                        bx = stepping ? qx : bx, by = stepping ? qy : by, bz = stepping ? qz : bz;
+                        bm = other ? s.m : bm, bk = other ? s.k : bk;
+                        b_alt = other ? s.alt : b_alt, b_e0 = other ? s.e0 : b_e0, b_e1 = other ? s.e1 : b_e1;
+                        ds0 = cross ? -ds : ((!stepping & same) ? t : ds0);
+                        ds1 = cross ? 0. : ((!stepping & other) ? t : ds1);
+                        halvings = stepping ? 0 : halvings + 1;
+                        state = cross ? ST_BISECT : state;
+                        my_steps += stepping ? 1 : 0;
+                        my_plain += accept ? 1 : 0;
+                        const bool located = (state == ST_BISECT) & !cross &
+                            (!(ds1 - ds0 > 1E-08) | (halvings > 1200));
+                        bool ended = accept;
+                        if (accept) {
+                                len += ds, k = s.k;
+                                s_alt = s.alt, s_e0 = s.e0, s_e1 = s.e1;
+                        }
+                        if (located) { /* [ref stepper.c:861-863] */
+                                bx = bx + dx * ds1, by = by + dy * ds1, bz = bz + dz * ds1;
+                                len += ds + ds1;
+                                m = bm, k = bk;
+                                s_alt = b_alt, s_e0 = b_e0, s_e1 = b_e1;
+                                state = ST_STEP;
+                                ended = true;
+                        }
+                        if (ended) { /* a generation is over */
+                                count++;
+                                if ((m < 0) || (count >= io.n_steps)) {
+                                        pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
+                                        alt[ray] = s_alt;
+                                        elev[2 * ray] = (m >= 0) ? s_e0 : 0., elev[2 * ray + 1] = (m >= 0) ? s_e1 : 0.;
+                                        index[2 * ray] = m, index[2 * ray + 1] = k;
+                                        length[ray] += len, steps[ray] += count;
+                                        my_rays++;
+                                        ray = -1;
+                                } else {
+                                        ds = d_step_length(v, s_alt, s_e0, s_e1, m);
+                                        d_isotropic((ull)(io.first + ray), (ull)(io.first_step + count), io.seed,
+                                            dx, dy, dz);
+                                }
+                        }
+                }
+        }
+        block_tally(stats, my_rays, my_steps, my_samples, my_plain);
+}
+
 __global__ void k_philox(long n, ull seed, ull stream, long first, unsigned * __restrict__ out)
 {
         for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n;
@@ -2844,6 +2992,42 @@ extern "C" int tamd_k_step_walk(struct tamd_view view, long n, double * pos, dou
         const StepWalk walk = { 1, seed, stream, first, length, steps };
         return run_step(view, n, pos, nullptr, nullptr, nullptr, alt, elev, nullptr, index,
             TURTLE_AMD_STEP_RESUME, cross, pg, stats, walk);
+}
+
+/* A whole walk in one launch (k_walk): every tile resident, nothing listed.
+ * stats are NOT zeroed (the caller does); queue[0] is. */
+extern "C" int tamd_k_walk(struct tamd_view view, long n, double * pos, double * alt, double * elev,
+    int * index, unsigned long long seed, long first, int first_step, int n_steps, double * length,
+    int * steps, unsigned long long * stats, unsigned long long * queue)
+{
+        if (tamd_dev_init()) return 1;
+        HIP_TRY(hipMemsetAsync(queue, 0, sizeof(ull), g_stream));
+        if (n <= 0) return 0;
+        const WalkIO io = { seed, first, first_step, n_steps };
+        const bool strict = g_math_strict || !view.fast_ok;
+#define WALK_CASE(MODE)                                                                        \
+        do {                                                                                   \
+                const void * kernel = strict ? (const void *)k_walk<MODE, false> :            \
+                                               (const void *)k_walk<MODE, true>;               \
+                long blocks = (long)g_cus * trace_blocks_per_cu(kernel);                       \
+                const long useful = (n + 255) / 256;                                           \
+                if (blocks > useful) blocks = useful;                                          \
+                if (strict)                                                                    \
+                        hipLaunchKernelGGL((k_walk<MODE, false>), dim3((unsigned)blocks), dim3(256), 0,   \
+                            g_stream, view, n, pos, alt, elev, index, length, steps, io, stats, queue);  \
+                else                                                                           \
+                        hipLaunchKernelGGL((k_walk<MODE, true>), dim3((unsigned)blocks), dim3(256), 0,    \
+                            g_stream, view, n, pos, alt, elev, index, length, steps, io, stats, queue);  \
+        } while (0)
+        if (view.mode == TAMD_MODE_ONE_MAP)
+                WALK_CASE(TAMD_MODE_ONE_MAP);
+        else if (view.mode == TAMD_MODE_ONE_STACK)
+                WALK_CASE(TAMD_MODE_ONE_STACK);
+        else
+                WALK_CASE(TAMD_MODE_GENERIC);
+#undef WALK_CASE
+        LAUNCH_CHECK("k_walk");
+        return 0;
 }
 
 extern "C" int tamd_k_philox(long n, unsigned long long seed, unsigned long long stream,

@@ -209,6 +209,11 @@ int tamd_k_step_walk(struct tamd_view view, long n, double * pos, double * alt,
     double * elev, int * index, unsigned long long seed, unsigned long long stream, long first,
     double * length, int * steps, int * cross_ray, double * cross_ds, struct tamd_paging pg,
     unsigned long long * stats, unsigned long long * queue);
+/* the same walk, all its generations in one launch, the rays' state in registers
+ * (every tile resident); stats are NOT zeroed */
+int tamd_k_walk(struct tamd_view view, long n, double * pos, double * alt, double * elev,
+    int * index, unsigned long long seed, long first, int first_step, int n_steps, double * length,
+    int * steps, unsigned long long * stats, unsigned long long * queue);
 int tamd_k_philox(long n, unsigned long long seed, unsigned long long stream,
     long first, unsigned * out);
 int tamd_k_isotropic(long n, unsigned long long seed, unsigned long long stream,

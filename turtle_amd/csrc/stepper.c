@@ -709,6 +709,20 @@ enum turtle_return turtle_stepper_scatter_n(struct turtle_stepper * stepper, lon
                 rc = tamd_stepper_flatten(stepper, message, sizeof(message));
                 if (rc < 0) rc = TURTLE_RETURN_LIBRARY_ERROR;
         }
+        /* every tile resident: the whole walk in one launch, the rays' state in
+         * registers (k_walk); else generation by generation, each in rounds over the
+         * rays that wait for a tile (TURTLE_AMD_WALK=steps: that form always) */
+        static int by_steps = -1;
+        if (by_steps < 0) {
+                const char * env = getenv("TURTLE_AMD_WALK");
+                by_steps = ((env != NULL) && (strcmp(env, "steps") == 0)) ? 1 : 0;
+        }
+        if ((rc == 0) && !by_steps && !stepper_is_paged(stepper) && (n_steps > 0)) {
+                if (tamd_k_walk(stepper->view, n, a.pos, a.alt, a.elev, a.index, seed, first_ray,
+                        first_step, n_steps, a.length, a.steps, stepper->d_stats, stepper->d_stats + 4))
+                        rc = TURTLE_RETURN_LIBRARY_ERROR;
+                n_steps = 0;
+        }
         for (k = 0; (rc == 0) && (k < n_steps); k++) {
                 a.stream = (unsigned long long)(first_step + k);
                 rc = stepper_rounds(stepper, n, &walk_round, &a, message, sizeof(message));
