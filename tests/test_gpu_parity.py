@@ -668,6 +668,7 @@ def test_scatter_n_is_the_step_loop(math, tmp_path):
         w2 = st.scatter(pos.copy(), 4242, 10, first_ray=17)
         w2 = st.scatter(None, 4242, K - 10, first_ray=17, first_step=10, state=w2)
         wd = st.scatter(torch.as_tensor(pos, device="cuda"), 4242, K, first_ray=17)
+        TA.synchronize()      # device arrays: the call returns once its launches are queued
         for got in (w2, {k: v.cpu().numpy() for k, v in wd.items()}):
             for key in ("position", "index", "steps", "length"):
                 assert np.array_equal(got[key], w[key]), key

@@ -2325,7 +2325,9 @@ __global__ void __launch_bounds__(256) k_walk(tamd_view v, long n, double * __re
                                 } else {
                                         bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
                                         s_alt = alt[ray], s_e0 = elev[2 * ray], s_e1 = elev[2 * ray + 1];
-                                        len = 0., count = 0, state = ST_STEP;
+                                        /* the sum goes on where it stands: the same roundings
+                                         * in one call as in several */
+                                        len = length[ray], count = 0, state = ST_STEP;
                                         ds = d_step_length(v, s_alt, s_e0, s_e1, m);
                                         d_isotropic((ull)(io.first + ray), (ull)io.first_step, io.seed, dx, dy, dz);
                                 }
@@ -2380,7 +2382,7 @@ __global__ void __launch_bounds__(256) k_walk(tamd_view v, long n, double * __re
                                         alt[ray] = s_alt;
                                         elev[2 * ray] = (m >= 0) ? s_e0 : 0., elev[2 * ray + 1] = (m >= 0) ? s_e1 : 0.;
                                         index[2 * ray] = m, index[2 * ray + 1] = k;
-                                        length[ray] += len, steps[ray] += count;
+                                        length[ray] = len, steps[ray] += count;
                                         my_rays++;
                                         ray = -1;
                                 } else {
