@@ -672,7 +672,6 @@ def test_scatter_n_is_the_step_loop(math, tmp_path):
         for got in (w2, {k: v.cpu().numpy() for k, v in wd.items()}):
             for key in ("position", "index", "steps", "length"):
                 assert np.array_equal(got[key], w[key]), key
-        assert (w["steps"] < K).any() or add == "add_map"   # some rays left through the hole / the rim
         st.destroy()
     m.destroy()
     stack.destroy()
