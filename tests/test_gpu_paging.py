@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 N_TILE = 1201
 TILES = [(la, lo) for la in range(40, 45) for lo in range(5, 10) if (la, lo) != (42, 7)]
-BUDGET = 16   # the smallest a stack goes (turtle_amd.h): 24 tiles do not fit
+BUDGET = 16   # 24 tiles do not fit
 
 
 @pytest.fixture(scope="module")
@@ -135,5 +135,186 @@ def test_single_steps_paged(mosaic_dir):
         for k in ("index", "position", "step", "altitude", "elevation"):
             assert np.array_equal(a[k], b[k]), (gen, k)
         assert paged.resident <= BUDGET
+    for o in (sf, sp, full, paged):
+        o.destroy()
+
+
+def test_reference_stack_test_tile_counts(tmp_path):
+    """The reference's own test of its stack [ref tests/test-turtle.c:628-690]: four
+    tiles of zeros, stack_size 3, scalar queries; the number of tiles in memory after
+    each one, clear and load."""
+    d = str(tmp_path / "four")
+    os.makedirs(d)
+    flat = np.zeros((1201, 1201), dtype=np.int16)
+    for la, lo in ((45, 2), (45, 3), (46, 2), (46, 3)):
+        with open(os.path.join(d, synth.hgt_name(la, lo, 1201)), "wb") as f:
+            f.write(synth.hgt_bytes(flat))
+    s = TA.Stack(d, 3)
+    assert s.resident == 0
+    for (la, lo), count in (((45.5, 3.5), 1), ((45.0, 3.5), 1), ((46.5, 3.5), 2), ((45.0, 3.5), 2)):
+        z, inside = s.elevation_scalar(la, lo)
+        assert (z, inside, s.resident) == (0.0, 1, count), (la, lo)
+    z, inside = s.elevation_scalar(45.5, 4.5)
+    assert inside == 0 and s.resident == 2
+    for (la, lo), count in (((45.5, 2.5), 3), ((46.5, 2.5), 3)):
+        z, inside = s.elevation_scalar(la, lo)
+        assert (z, inside, s.resident) == (0.0, 1, count), (la, lo)
+    s.clear()
+    assert s.resident == 0
+    s.elevation_scalar(45.5, 2.5)
+    assert s.resident == 1
+    s.load()
+    assert s.resident == 3
+    s.clear()
+    s.load()
+    s.load()
+    assert s.resident == 3
+    s.destroy()
+    s = TA.Stack(d, 0)
+    s.load()
+    assert s.resident == 4
+    s.destroy()
+
+
+@pytest.mark.parametrize("size", [1, 3, 8])
+@pytest.mark.parametrize("math", ["strict", "fast"])
+def test_trace_paged_against_the_oracle(mosaic_dir, math, size):
+    """Traces through a stack that keeps `size` tiles (the reference's test uses 3)
+    against the CPU restatement with every tile in memory -- directly, not through the
+    all-resident GPU stack: rays that go from tile to tile, rays whose bisection
+    straddles a seam, rays over the hole; and the stack is back within its size when
+    the call returns."""
+    import terrains as T
+    from oracle import ffi as O
+    TA.set_math(math)
+    try:
+        geo = T.mosaic_oracle(TILES, N_TILE, 40, 5, 5, 5)
+        paged = TA.Stack(mosaic_dir, size)
+        sp = TA.Stepper()
+        sp.add_stack(paged, 0.0)
+        rng = np.random.default_rng(17)
+        n = 3000
+        lat, lon = rng.uniform(40.1, 44.9, n), rng.uniform(5.1, 9.9, n)
+        # a third of the rays start within 30 m of a seam, heading across it
+        k = n // 3
+        lat[:k] = np.round(lat[:k]) + rng.uniform(-3e-4, 3e-4, k)
+        az, el = rng.uniform(0, 360, n), rng.uniform(-12.0, 2.0, n)
+        p, di = geo.position(lat, lon, 400.0)
+        keep = di == 0
+        p, d = p[keep], O.ecef_from_horizontal(lat, lon, az, el)[keep]
+        ref = geo.trace(p, d, threads=8)
+        pg, dg = sp.position(lat, lon, 400.0)
+        assert np.array_equal(dg == 0, keep) and np.array_equal(pg[keep], p)
+        assert paged.resident <= size
+        t = sp.trace(p.copy(), d)
+        assert paged.resident <= size
+        flipped = t["index"][:, 0] != ref["index"][:, 0]
+        rel = np.abs(t["length"] - ref["length"]) / np.maximum(ref["length"], 1e-300)
+        assert flipped.sum() <= 1 and (rel[~flipped] <= 1e-6).all(), (int(flipped.sum()), rel[~flipped].max())
+        if math == "strict":
+            assert (np.abs(t["n_steps"] - ref["n_steps"])[~flipped] <= 1).all()
+        # single steps page too, and agree with the oracle's
+        o = geo.step(p, d)
+        g = sp.step(p.copy(), d)
+        same = g["index"][:, 0] == o["index"][:, 0]
+        assert (~same).sum() <= 1
+        assert np.abs(g["step"][same] - o["step"][same]).max() <= 1e-6 * max(1.0, o["step"][same].max())
+        assert paged.resident <= size
+        sp.destroy()
+        paged.destroy()
+    finally:
+        TA.set_math("fast")
+
+
+def test_client_on_a_locked_stack(tmp_path):
+    """SURVEY a10 [ref client.c:99-188, tests/test-turtle.c:697-775]: a locked stack of
+    size 1, its client gives the stack's answers (lock and unlock called in pairs
+    around every tile change), the PATH_ERROR text for a missing tile; a stepper over
+    the locked stack creates its own client and traces as over an unlocked one."""
+    import ctypes as C
+    from turtle_amd import binding as Bn
+    d = str(tmp_path / "four")
+    os.makedirs(d)
+    for la, lo in ((45, 2), (45, 3), (46, 2), (46, 3)):
+        synth.write_hgt(d, la, lo, N_TILE)
+    LOCKER = C.CFUNCTYPE(C.c_int)
+    calls = []
+    lock = LOCKER(lambda: (calls.append("lock"), 0)[1])
+    unlock = LOCKER(lambda: (calls.append("unlock"), 0)[1])
+    L = TA.lib()
+    locked, plain = TA.Stack(d, 1, lock, unlock), TA.Stack(d, 0)
+    plain.load()
+    h = C.c_void_p()
+    Bn._check(L.turtle_client_create(C.byref(h), locked.h))
+
+    def client_elevation(la, lo, want_inside=True):
+        z, inside = C.c_double(-1.0), C.c_int(-1)
+        rc = L.turtle_client_elevation(h, C.c_double(la), C.c_double(lo), C.byref(z),
+                                       C.byref(inside) if want_inside else None)
+        Bn._check(rc)
+        return z.value, inside.value
+
+    for la, lo in ((45.5, 3.5), (45.0, 3.5), (46.5, 3.5), (45.0, 3.5), (45.5, 2.5), (46.5, 2.5),
+                   (45.73, 2.11), (46.0, 3.0)):
+        before = len(calls)
+        assert client_elevation(la, lo) == plain.elevation_scalar(la, lo), (la, lo)
+        new = calls[before:]
+        assert new.count("lock") == new.count("unlock") and locked.resident <= 1
+    assert "lock" in calls
+    assert client_elevation(45.5, 4.5)[1] == 0                       # outside: no error with `inside`
+    Bn._check(L.turtle_client_clear(h))
+    assert client_elevation(45.5, 3.5) == plain.elevation_scalar(45.5, 3.5)
+    with pytest.raises(TA.TurtleError) as e:                          # [ref test-turtle.c:764-771]
+        client_elevation(45.5, 4.5, want_inside=False)
+    assert e.value.name == "PATH_ERROR"
+    assert "turtle_client_elevation" in str(e.value) and f"missing elevation data in `{d}'" in str(e.value)
+    Bn._check(L.turtle_client_destroy(C.byref(h)))
+    # the stepper's own client: traces over the locked stack == over the unlocked one
+    sl, su = TA.Stepper(), TA.Stepper()
+    sl.add_stack(locked, 0.0)
+    su.add_stack(plain, 0.0)
+    lat, lon, az, el = synth.uniform_rays(4000, (45.0, 47.0), (2.0, 4.0), seed=3)
+    p, di = su.position(lat, lon, 300.0)
+    pl, dl = sl.position(lat, lon, 300.0)
+    assert np.array_equal(p, pl) and np.array_equal(di, dl) and (di == 0).all()
+    dirs = TA.ecef_from_horizontal(lat, lon, az, el)
+    TA.set_math("strict")
+    try:
+        before = len(calls)
+        a, b = su.trace(p.copy(), dirs), sl.trace(p.copy(), dirs)
+        new = calls[before:]
+    finally:
+        TA.set_math("fast")
+    for key in ("index", "length", "n_steps", "position"):
+        assert np.array_equal(a[key], b[key]), key
+    assert new.count("lock") == new.count("unlock") >= 1 and locked.resident <= 1
+    for o in (sl, su, locked, plain):
+        o.destroy()
+
+
+def test_paged_trace_on_device_arrays_without_outputs(mosaic_dir):
+    """A paged trace keeps each waiting ray's path length and step count in arrays of
+    its own when the caller asks for neither -- also when the rays are device arrays
+    (nothing staged, the library's arena not yet sized) and the batch is large."""
+    import torch
+    full, paged = TA.Stack(mosaic_dir, 0), TA.Stack(mosaic_dir, 4)
+    full.load()
+    sf, sp = TA.Stepper(), TA.Stepper()
+    sf.add_stack(full, 0.0)
+    sp.add_stack(paged, 0.0)
+    n = 600_000
+    rng = np.random.default_rng(5)
+    lat, lon = rng.uniform(40.1, 41.9, n), rng.uniform(5.1, 6.9, n)
+    az, el = rng.uniform(0, 360, n), rng.uniform(-20.0, -5.0, n)
+    p, di = sf.position(lat, lon, 300.0)
+    d = TA.ecef_from_horizontal(lat, lon, az, el)
+    a = sf.trace(p.copy(), d, want=())
+    tp, td = torch.as_tensor(p, device="cuda"), torch.as_tensor(d, device="cuda")
+    b = sp.trace(tp, td, want=())
+    TA.synchronize()
+    assert b["length"] is None and b["n_steps"] is None
+    assert np.array_equal(a["index"], b["index"].cpu().numpy())
+    assert np.abs(a["position"] - b["position"].cpu().numpy()).max() < 1e-5
+    assert paged.resident <= 4
     for o in (sf, sp, full, paged):
         o.destroy()

@@ -129,8 +129,8 @@ def test_stack_directory_scan(tmp_path):
 
 def test_stack_residency_budget(tmp_path):
     """stack_size, turtle_stack_load / clear [ref stack.c:150, :228-297]: tiles come
-    in, in directory order, up to the limit (never below 9 here: a 3 x 3
-    neighbourhood); without a limit all of them."""
+    in, in directory order, up to the limit the caller gave; without a limit all of
+    them [ref tests/test-turtle.c:664-684: 3 of 4 with size 3, 4 with size 0]."""
     d = os.path.join(tmp_path, "grid")
     tiles = [(la, lo) for la in range(40, 45) for lo in range(5, 10) if (la, lo) != (42, 7)]
     for la, lo in tiles:
@@ -142,7 +142,7 @@ def test_stack_residency_budget(tmp_path):
     s.clear()
     assert s.resident == 0
     s.destroy()
-    for size, expect in ((20, 20), (16, 16), (2, 16)):
+    for size, expect in ((20, 20), (16, 16), (3, 3), (1, 1)):
         s = TA.Stack(d, size)
         s.load()
         assert s.resident == expect

@@ -2269,8 +2269,11 @@ struct WalkIO {
         int n_steps;     /* generations to take */
 };
 
+#ifndef WALK_WAVES_ATTR
+#define WALK_WAVES_ATTR
+#endif
 template <int MODE, bool FAST>
-__global__ void __launch_bounds__(256) k_walk(tamd_view v, long n, double * __restrict__ pos,
+__global__ void __launch_bounds__(256) WALK_WAVES_ATTR k_walk(tamd_view v, long n, double * __restrict__ pos,
     double * __restrict__ alt, double * __restrict__ elev, int * __restrict__ index,
     double * __restrict__ length, int * __restrict__ steps, WalkIO io, ull * __restrict__ stats,
     ull * __restrict__ queue)

@@ -97,10 +97,11 @@ struct turtle_stack {
         struct tamd_view view;
 };
 
-/* Tiles the stack may keep in memory [ref stack.c:150]: max_size (at least
- * TAMD_STACK_FLOOR), or no limit */
-#define TAMD_STACK_FLOOR 16
+/* Tiles the stack keeps in memory between calls [ref stack.c:150]: max_size, or
+ * no limit; tamd_stack_trim brings it back there when a batch call ends (while
+ * it runs, the tiles its first waiting item needs stay, whatever their number) */
 int tamd_stack_budget(const struct turtle_stack * stack);
+void tamd_stack_trim(struct turtle_stack * stack);
 /* Are there tiles with a file that are not in memory? */
 int tamd_stack_is_paged(const struct turtle_stack * stack);
 /* [ref stack.c:257-297] tiles in directory order until the budget is reached;

@@ -200,13 +200,39 @@ enum turtle_return turtle_stack_clear(struct turtle_stack * stack)
         return TURTLE_RETURN_SUCCESS;
 }
 
-/* never below 16: a lookup near a seam consults the boxes of the 3 x 3 tiles
- * around it, and a ray's step (the bisection of a crossing) can need two such
- * neighbourhoods, side by side, resident together */
+/* Tiles the stack keeps in memory between calls [ref stack.c:150]: what the
+ * caller asked for.  While a batch runs the tiles its first waiting item needs
+ * stay whatever their number (a lookup near a seam consults the boxes of the
+ * 3 x 3 tiles around it, a bisection can need two such neighbourhoods: up to 16)
+ * -- as the reference's stack exceeds its size by the tiles its clients have
+ * pinned [ref stack.c:433-442: only unpinned tiles go] -- and the stack is
+ * trimmed back when the call ends (tamd_stack_trim). */
 int tamd_stack_budget(const struct turtle_stack * s)
 {
-        if (s->max_size <= 0) return INT_MAX;
-        return (s->max_size < TAMD_STACK_FLOOR) ? TAMD_STACK_FLOOR : s->max_size;
+        return (s->max_size <= 0) ? INT_MAX : s->max_size;
+}
+
+/* the least recently wanted tiles go until the stack is within its size */
+void tamd_stack_trim(struct turtle_stack * s)
+{
+        const int n = s->latitude_n * s->longitude_n, budget = tamd_stack_budget(s);
+        if (s->n_loaded <= budget) return;
+        if (s->lock != NULL) (void)s->lock();
+        while (s->n_loaded > budget) {
+                int i, out = -1;
+                for (i = 0; i < n; i++) {
+                        if (s->tile[i] == NULL) continue;
+                        if ((out < 0) || (s->stamp[i] < s->stamp[out])) out = i;
+                }
+                if (out < 0) break;
+                struct turtle_map * m = s->tile[out];
+                m->stack = NULL; /* do not walk back into the table */
+                turtle_map_destroy(&m);
+                s->tile[out] = NULL;
+                s->n_loaded--;
+                tamd_geometry_epoch++;
+        }
+        if (s->unlock != NULL) (void)s->unlock();
 }
 
 int turtle_amd_stack_resident(const struct turtle_stack * stack) { return stack->n_loaded; }
@@ -260,7 +286,27 @@ int tamd_stack_preload(struct turtle_stack * s, char * message, size_t size)
         return TURTLE_RETURN_SUCCESS;
 }
 
+static int stack_page_in(struct turtle_stack * s, const unsigned * wanted,
+    const unsigned * wanted_first, int first_bit, char * message, size_t size);
+
+/* Tiles come and go under the stack's lock, when it has one [ref client.c:126-
+ * 188: the reference's clients take it around every change of tile] */
 int tamd_stack_page_in(struct turtle_stack * s, const unsigned * wanted,
+    const unsigned * wanted_first, int first_bit, char * message, size_t size)
+{
+        if ((s->lock != NULL) && (s->lock() != 0)) {
+                snprintf(message, size, "could not acquire the lock");
+                return -TURTLE_RETURN_LOCK_ERROR;
+        }
+        int rc = stack_page_in(s, wanted, wanted_first, first_bit, message, size);
+        if ((s->unlock != NULL) && (s->unlock() != 0) && (rc >= 0)) {
+                snprintf(message, size, "could not release the lock");
+                rc = -TURTLE_RETURN_UNLOCK_ERROR;
+        }
+        return rc;
+}
+
+static int stack_page_in(struct turtle_stack * s, const unsigned * wanted,
     const unsigned * wanted_first, int first_bit, char * message, size_t size)
 {
         const int n = s->latitude_n * s->longitude_n, budget = tamd_stack_budget(s);
@@ -293,9 +339,11 @@ int tamd_stack_page_in(struct turtle_stack * s, const unsigned * wanted,
                                     ((DEMAND(i) == DEMAND(out)) && (s->stamp[i] < s->stamp[out])))
                                         out = i;
                         }
-                        /* ... and only for a tile in more demand (or the first item's) */
-                        if ((out < 0) || (!first && (DEMAND(out) >= DEMAND(want)))) break;
-                        stack_drop_tile(s, out);
+                        /* ... and only for a tile in more demand; the first item's come in
+                         * whatever has to go -- or nothing, if all that is in memory is
+                         * its own (the stack is trimmed when the call ends) */
+                        if (!first && ((out < 0) || (DEMAND(out) >= DEMAND(want)))) break;
+                        if (out >= 0) stack_drop_tile(s, out);
                 }
                 const int rc = stack_load_tile(s, want, message, size);
                 if (rc != TURTLE_RETURN_SUCCESS) return -rc;
@@ -441,6 +489,7 @@ static int stack_rounds(struct stack_call * call, char * message, size_t size)
                 }
         }
         tamd_pager_end(&pager);
+        tamd_stack_trim(s);
         return rc;
 }
 

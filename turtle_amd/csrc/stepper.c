@@ -483,6 +483,11 @@ static int stepper_rounds(struct turtle_stepper * stepper, long n, stepper_round
                 }
         }
         tamd_pager_end(&pager);
+        if (pager.rounds > 1) {
+                int i;
+                for (i = 0; i < stepper->n_data; i++)
+                        if (stepper->data[i].kind == TAMD_STACK) tamd_stack_trim(stepper->data[i].stack);
+        }
         return rc;
 }
 
@@ -790,10 +795,18 @@ enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long 
         if (stepper_is_paged(stepper) && !args.scratch)
                 return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR,
                     "a batch this large cannot run over stacks with tiles left to page in");
-        if (stepper_is_paged(stepper) && (n > 0) &&
-            (((args.length == NULL) && tamd_scratch_get(&args.length, nb)) ||
-                ((args.n_steps == NULL) && tamd_scratch_get(&args.n_steps, n * sizeof(int)))))
-                return TAMD_RAISE_DEVICE();
+        if (stepper_is_paged(stepper) && (n > 0) && ((args.length == NULL) || (args.n_steps == NULL))) {
+                if (space == TURTLE_AMD_DEVICE) {
+                        /* nothing was staged: the arena is neither sized nor reset yet */
+                        void * all;
+                        tamd_scratch_reset();
+                        if (tamd_scratch_get(&all, nb + n * sizeof(int) + 1024)) return TAMD_RAISE_DEVICE();
+                        tamd_scratch_reset();
+                }
+                if (((args.length == NULL) && tamd_scratch_get(&args.length, nb)) ||
+                    ((args.n_steps == NULL) && tamd_scratch_get(&args.n_steps, n * sizeof(int))))
+                        return TAMD_RAISE_DEVICE();
+        }
         char message[4200];
         const int rc = stepper_rounds(stepper, n, &trace_round, &args, message, sizeof(message));
         if (rc == TURTLE_RETURN_LIBRARY_ERROR) return TAMD_RAISE_DEVICE();
