@@ -204,7 +204,7 @@ def test_trace_paged_against_the_oracle(mosaic_dir, math, size):
         p, d = p[keep], O.ecef_from_horizontal(lat, lon, az, el)[keep]
         ref = geo.trace(p, d, threads=8)
         pg, dg = sp.position(lat, lon, 400.0)
-        assert np.array_equal(dg == 0, keep) and np.array_equal(pg[keep], p)
+        assert np.array_equal(dg == 0, keep) and np.abs(pg[keep] - p).max() < 1e-8   # OCML vs glibc sin/cos
         assert paged.resident <= size
         t = sp.trace(p.copy(), d)
         assert paged.resident <= size

@@ -868,7 +868,16 @@ __device__ __forceinline__ int d_stack_tile(const tamd_view & v, const tamd_stac
         const int * tiles = v.tiles + st.tile_first;
         int tile = tiles[cy * st.nlon + cx];
         f.centre = st.tile_first + cy * st.nlon + cx, f.stride = st.nlon, f.mask = 1 << 4;
-        if (tile == TAMD_TILE_PAGED) return kTileFault;
+        /* Outside the directory's range the formula [ref stack.c:413-424] names no
+         * tile, and the reference loads none: only tiles that ARE in memory can
+         * answer (its list scan); a tile that is not is wanted only for a point in
+         * the range, or within rounding of its rim. */
+        const bool in_range = (fx > -kRimGuard) && (fx < st.nlon + kRimGuard) && (fy > -kRimGuard) &&
+            (fy < st.nlat + kRimGuard);
+        if (tile == TAMD_TILE_PAGED) {
+                if (in_range) return kTileFault;
+                tile = TAMD_TILE_NONE;
+        }
         if ((tile < 0) || !d_tile_holds(v.grids[tile], latitude, longitude)) {
                 /* rare: a seam, the rim, or a hole in the mosaic.  A neighbour
                  * that is not resident may be the one whose box holds the point:
@@ -881,7 +890,7 @@ __device__ __forceinline__ int d_stack_tile(const tamd_view & v, const tamd_stac
                                 const int t = tiles[iy * st.nlon + ix];
                                 if (t == TAMD_TILE_NONE) continue;
                                 mask |= 1 << (3 * (j + 1) + (i + 1));
-                                if (t == TAMD_TILE_PAGED) paged = 1;
+                                if ((t == TAMD_TILE_PAGED) && in_range) paged = 1;
                         }
                 }
                 if (paged) {
