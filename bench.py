@@ -109,7 +109,7 @@ class Terrain:
     """The synthetic tiles of a workload, written as .hgt files and loaded through
     the C API; the node arrays are kept for the CPU checker."""
 
-    def __init__(self, TA, tiles, use_stack, rank):
+    def __init__(self, TA, tiles, use_stack, rank, stack_size=0):
         from turtle_amd import synth
         self.tiles, self.use_stack = tiles, use_stack
         lat0, lon0, nlat, nlon = tiles
@@ -125,8 +125,8 @@ class Terrain:
             self.nodes = dict(pool.map(make, cells))
         self.stepper = TA.Stepper()
         if use_stack:
-            self.handle = TA.Stack(self.tmp, 0)
-            self.handle.load()                         # every tile resident: no paging rounds
+            self.handle = TA.Stack(self.tmp, stack_size)
+            self.handle.load()      # up to stack_size tiles (0: all of them: no paging rounds)
             self.stepper.add_stack(self.handle, 0.0)
         else:
             self.handle = TA.Map.load(os.path.join(self.tmp, synth.hgt_name(lat0, lon0)))
@@ -233,7 +233,7 @@ def run_workload(name, args, env, headline):
 
     world, rank, dev = env["world"], env["rank"], env["dev"]
     tiles, use_stack, default_rays, text = WORKLOADS[name]
-    terrain = Terrain(TA, tiles, use_stack, rank)
+    terrain = Terrain(TA, tiles, use_stack, rank, args.stack_size if use_stack else 0)
     stepper = terrain.stepper
     n_block = args.rays or default_rays
     blocks = max(1, args.blocks)
@@ -358,7 +358,10 @@ def run_workload(name, args, env, headline):
         valu_frac = (4.0 * valu / (simds * kernel_ms * 1e-3 * VALU_CLOCK_HZ)) if valu else None
         out = {
             "value": value, "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
-            "config": {"workload": text, "rays_per_gpu": n, "max_steps": args.max_steps,
+            "config": {"workload": text + (f" -- stack_size {args.stack_size}: tiles paged host->HBM "
+                                           f"by demand, {stepper.rounds} rounds in the last pass"
+                                           if (use_stack and args.stack_size) else ""),
+                       "rays_per_gpu": n, "max_steps": args.max_steps,
                        "slope": 0.4, "resolution": 1e-2, "math": TA.get_math(),
                        "parallelism": f"rays x{world}"},
             "kernel": kernel,
@@ -433,6 +436,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=1,
                     help="blocks of --rays rays per rank: --gpus 1 --blocks 8 traces the ray "
                          "array an 8-rank run shards (same tally, to the bit)")
+    ap.add_argument("--stack-size", type=int, default=0,
+                    help="c3 / c5: tiles the stack keeps in memory (0: all; SURVEY's second C3 leg: 8)")
     ap.add_argument("--max-steps", type=int, default=100_000)
     ap.add_argument("--scatter-steps", type=int, default=256, help="c5: steps per ray")
     ap.add_argument("--sort", type=int, default=0,
@@ -483,14 +488,16 @@ def main():
     head = run_workload(head_name, args, env, headline=True)
     also = args.also
     if also is None:
-        also = "c3,c5" if (args.workload is None and world == 1) else "none"
+        also = "c3,c3@8,c5" if (args.workload is None and world == 1) else "none"
     extra = {}
     for name in [w for w in also.split(",") if w and w != "none"]:
         sub = argparse.Namespace(**vars(args))
-        sub.rays, sub.blocks, sub.sort, sub.sort_steps = 0, 1, 0, 0
+        sub.rays, sub.blocks, sub.sort, sub.sort_steps, sub.stack_size = 0, 1, 0, 0, 0
+        if name.endswith("@8"):      # C3's second leg: the same workload, 8 of its 16 tiles resident
+            name, sub.stack_size = name[:-2], 8
         r = run_workload(name, sub, env, headline=False)
         if rank == 0:
-            extra[name] = {"metric": "ray-steps/s", "value": r["value"], "passes": 1,
+            extra[name + (f"_stack_size_{sub.stack_size}" if sub.stack_size else "")] = {"metric": "ray-steps/s", "value": r["value"], "passes": 1,
                            "ms_per_pass": r["ms_per_step"], "config": r["config"],
                            "kernel": r["kernel"], "roofline": r["roofline"],
                            **({"parity": r["parity"]} if "parity" in r else {}),

@@ -412,6 +412,11 @@ TURTLE_API enum turtle_return turtle_stepper_trace_n(
 TURTLE_API enum turtle_return turtle_stepper_trace_stats(
     struct turtle_stepper * stepper, unsigned long long stats[4]);
 
+/* Rounds the last batch call on this stepper took: 1 when every tile it needed was
+ * in memory, one more each time tiles had to come in for rays that waited (paged
+ * stacks: stack_size below the tiles a batch touches). */
+TURTLE_API int turtle_amd_stepper_rounds(const struct turtle_stepper * stepper);
+
 /* Reduce trace results for a multi-GPU tally: hits[m + 1] counts
  * rays whose final index[0] == m, for m in [-1, n_media); histogram[b] counts
  * path lengths in bin b of n_bins linear bins over [0, length_max), the last

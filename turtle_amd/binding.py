@@ -559,6 +559,11 @@ class Stepper:
                                             _ptr(d), max_steps, _ptr(index), _ptr(length),
                                             _ptr(nsteps), 0, DEVICE))
 
+    @property
+    def rounds(self):
+        """rounds the last batch call took (1: no tile had to be paged in)"""
+        return int(lib().turtle_amd_stepper_rounds(self.h))
+
     def trace_stats(self):
         s = (C.c_ulonglong * 4)()
         _check(lib().turtle_stepper_trace_stats(self.h, s))

@@ -157,6 +157,7 @@ struct turtle_stepper {
         int * d_parked;               /* scratch of the batch calls: ray ids ... */
         double * d_scratch_ds;        /* ... and one double each (same block) */
         long parked_capacity;
+        int last_rounds;              /* rounds the last batch call took (1: nothing was paged in) */
 };
 
 /* Any change to what kernels may read (map nodes, tiles, layers) bumps this. */

@@ -483,6 +483,7 @@ static int stepper_rounds(struct turtle_stepper * stepper, long n, stepper_round
                 }
         }
         tamd_pager_end(&pager);
+        stepper->last_rounds = (pager.rounds > 0) ? pager.rounds : 1;
         if (pager.rounds > 1) {
                 int i;
                 for (i = 0; i < stepper->n_data; i++)
@@ -818,6 +819,8 @@ enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long 
                 return TAMD_RAISE_DEVICE();
         return TURTLE_RETURN_SUCCESS;
 }
+
+int turtle_amd_stepper_rounds(const struct turtle_stepper * stepper) { return stepper->last_rounds; }
 
 enum turtle_return turtle_stepper_trace_stats(
     struct turtle_stepper * stepper, unsigned long long stats[4])
