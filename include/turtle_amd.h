@@ -254,12 +254,21 @@ enum turtle_amd_space {
                                  only enqueues work on the library stream */
 };
 
-/* Device / stream management.  One process drives one GPU (one process per
- * GPU is the multi-GPU model).  The default device is
- * $LOCAL_RANK if set, else 0. */
+/* Device / stream management, per calling THREAD: the device a thread's calls
+ * run on ($LOCAL_RANK if set, else 0, until it calls turtle_amd_device_set), its
+ * stream, its arithmetic mode and the scratch memory its calls use are its own.
+ * The reference's threading rule carries over [ref include/turtle.h:129-132,
+ * :620-626, examples/example-pthread.c]: a stepper (and its client) belongs to
+ * one thread at a time; maps and stacks may be shared -- a stack whose tiles can
+ * change (stack_size below its number of files) with lock / unlock callbacks, as
+ * in the reference.  One process may drive one GPU (one process per GPU: what
+ * bench.py does) or several, a thread each: maps and tiles get a copy on every
+ * device that uses them.  A worker thread calls turtle_amd_thread_release before
+ * it ends (its stream and scratch memory are freed then, never behind its back). */
 TURTLE_API int turtle_amd_device_count(void);
 TURTLE_API enum turtle_return turtle_amd_device_set(int device);
 TURTLE_API int turtle_amd_device_get(void);
+TURTLE_API void turtle_amd_thread_release(void);
 /* Use a caller-owned hipStream_t (e.g. torch's current stream) for every
  * subsequent launch; NULL restores the library's own stream. */
 TURTLE_API enum turtle_return turtle_amd_stream_set(void * hip_stream);

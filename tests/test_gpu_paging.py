@@ -318,3 +318,91 @@ def test_paged_trace_on_device_arrays_without_outputs(mosaic_dir):
     assert paged.resident <= 4
     for o in (sf, sp, full, paged):
         o.destroy()
+
+
+def test_threads_share_a_map_and_a_locked_stack(tmp_path):
+    """The reference's threading pattern [ref examples/example-pthread.c:66-125]: a
+    stepper (and a client) per thread over a shared map / a shared stack with lock
+    callbacks whose tiles come and go (stack_size 2 over 4 files).  Each thread's
+    device context (stream, scratch arena, tables) is its own: the answers are those
+    of one thread doing the same calls, bit for bit."""
+    import ctypes as C
+    import threading
+    from turtle_amd import binding as Bn
+    d = str(tmp_path / "four")
+    os.makedirs(d)
+    for la, lo in ((45, 2), (45, 3), (46, 2), (46, 3)):
+        synth.write_hgt(d, la, lo, N_TILE)
+    tile = TA.Map.load(os.path.join(d, synth.hgt_name(45, 3, N_TILE)))
+    mutex = threading.Lock()
+    LOCKER = C.CFUNCTYPE(C.c_int)
+    lock = LOCKER(lambda: (mutex.acquire(), 0)[1])
+    unlock = LOCKER(lambda: (mutex.release(), 0)[1])
+    shared = TA.Stack(d, 2, lock, unlock)
+    L = TA.lib()
+    n_threads, n = 4, 3000
+
+    def work(seed, out):
+        try:
+            rng = np.random.default_rng(seed)
+            # (a) a stepper of its own over the shared map: batches and scalar steps
+            sm = TA.Stepper()
+            sm.add_map(tile, 0.0)
+            lat, lon = rng.uniform(45.1, 45.9, n), rng.uniform(3.1, 3.9, n)
+            az, el = rng.uniform(0, 360, n), rng.uniform(-10.0, -1.0, n)
+            p, _ = sm.position(lat, lon, 300.0)
+            dirs = TA.ecef_from_horizontal(lat, lon, az, el)
+            out["map_trace"] = sm.trace(p.copy(), dirs)
+            q, steps = p[0].copy(), []
+            for _ in range(40):
+                r = sm.step_scalar(q, dirs[0])
+                q = r["position"]
+                steps.append((r["step"], r["altitude"], int(r["index"][0])))
+            out["map_steps"] = steps
+            # (b) a client and a stepper of its own over the shared, locked stack
+            h = C.c_void_p()
+            Bn._check(L.turtle_client_create(C.byref(h), shared.h))
+            zs = []
+            for la, lo in zip(rng.uniform(45.0, 47.0, 60), rng.uniform(2.0, 4.0, 60)):
+                z, inside = C.c_double(), C.c_int()
+                Bn._check(L.turtle_client_elevation(h, C.c_double(la), C.c_double(lo), C.byref(z),
+                                                    C.byref(inside)))
+                zs.append((z.value, inside.value))
+            out["client"] = zs
+            Bn._check(L.turtle_client_destroy(C.byref(h)))
+            ss = TA.Stepper()
+            ss.add_stack(shared, 0.0)
+            lat, lon = rng.uniform(45.1, 46.9, n), rng.uniform(2.1, 3.9, n)
+            p, di = ss.position(lat, lon, 300.0)
+            out["stack_di"] = di
+            out["stack_trace"] = ss.trace(p.copy(), TA.ecef_from_horizontal(lat, lon, az, el))
+            sm.destroy()
+            ss.destroy()
+        except BaseException as e:      # noqa: BLE001 -- reported by the main thread
+            out["error"] = repr(e)
+        finally:
+            L.turtle_amd_thread_release()
+
+    TA.set_math("strict")     # per thread: the workers below run the default (fast)
+    TA.set_math("fast")
+    alone = [dict() for _ in range(n_threads)]
+    for i in range(n_threads):
+        t = threading.Thread(target=work, args=(100 + i, alone[i]))   # one at a time
+        t.start()
+        t.join()
+    together = [dict() for _ in range(n_threads)]
+    threads = [threading.Thread(target=work, args=(100 + i, together[i])) for i in range(n_threads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for a, b in zip(alone, together):
+        assert "error" not in a and "error" not in b, (a.get("error"), b.get("error"))
+        assert a["map_steps"] == b["map_steps"] and a["client"] == b["client"]
+        assert np.array_equal(a["stack_di"], b["stack_di"])
+        for key in ("map_trace", "stack_trace"):
+            for k in ("index", "length", "n_steps", "position"):
+                assert np.array_equal(a[key][k], b[key][k]), (key, k)
+    assert shared.resident <= 2 and not mutex.locked()
+    shared.destroy()
+    tile.destroy()

@@ -9,12 +9,15 @@ int turtle_amd_device_count(void) { return tamd_dev_count(); }
 enum turtle_return turtle_amd_device_set(int device)
 {
         TAMD_ERROR_INIT(&turtle_amd_device_set);
+        /* the calling THREAD's device from here on: its steppers rebuild their tables
+         * there at their next call, maps and tiles get a copy there when first needed */
         if (tamd_dev_select(device)) return TAMD_RAISE_DEVICE();
-        tamd_geometry_epoch++; /* tables of another device are not ours */
         return TURTLE_RETURN_SUCCESS;
 }
 
 int turtle_amd_device_get(void) { return tamd_dev_current(); }
+
+void turtle_amd_thread_release(void) { tamd_dev_release(); }
 
 enum turtle_return turtle_amd_stream_set(void * hip_stream)
 {

@@ -2468,14 +2468,39 @@ __global__ void __launch_bounds__(256) k_tally(long n, const int * __restrict__ 
 /*                         host side of the device layer                    */
 /* ======================================================================== */
 
+/* Per host THREAD: the device it works on, its stream, its scratch arena and
+ * its blocks of bookkeeping memory.  The reference's rule is one stepper (and one
+ * client) per thread over shared maps and stacks [ref include/turtle.h:129-132,
+ * :620-626, examples/example-pthread.c:66-125]; here a thread also has a device:
+ * the one LOCAL_RANK names (else 0) until it calls turtle_amd_device_set, so one
+ * process can drive several GPUs, a thread each.  What threads share -- map
+ * nodes, a stack's tiles -- is uploaded per device and changed under one lock
+ * (host.h: tamd_geometry_lock). */
+struct Ctx {
+        int device = -1, cus = 0;
+        hipStream_t own_stream = nullptr, stream = nullptr;
+        int math_strict = 0;
+        void * scratch = nullptr;
+        size_t scratch_size = 0, scratch_used = 0;
+        void * block[2] = { nullptr, nullptr }; /* grow-only: the pager's lists, a stack's own tables */
+        size_t block_size[2] = { 0, 0 };
+        void release()
+        {
+                if (device < 0) return;
+                if (hipSetDevice(device) != hipSuccess) return;
+                if (own_stream != nullptr) (void)hipStreamSynchronize(own_stream), (void)hipStreamDestroy(own_stream);
+                if (scratch != nullptr) (void)hipFree(scratch);
+                for (int i = 0; i < 2; i++)
+                        if (block[i] != nullptr) (void)hipFree(block[i]);
+                own_stream = stream = nullptr, scratch = nullptr, scratch_size = scratch_used = 0;
+                block[0] = block[1] = nullptr, block_size[0] = block_size[1] = 0;
+        }
+};
 static thread_local char g_error[512] = "";
-static int g_device = -1;
-static int g_cus = 0;
-static hipStream_t g_own_stream = nullptr;
-static hipStream_t g_stream = nullptr;
-static int g_math_strict = 0;
-static void * g_scratch = nullptr;
-static size_t g_scratch_size = 0, g_scratch_used = 0;
+static thread_local Ctx g_ctx;
+#define g_stream (g_ctx.stream)
+#define g_cus (g_ctx.cus)
+#define g_math_strict (g_ctx.math_strict)
 
 static int fail(const char * what, hipError_t e)
 {
@@ -2512,7 +2537,10 @@ extern "C" int tamd_dev_select(int device)
                     "invalid device index %d (have %d)", device, count);
                 return 1;
         }
-        HIP_TRY(hipSetDevice(device));
+        if (g_ctx.device == device) {
+                HIP_TRY(hipSetDevice(device));
+                return 0;
+        }
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -2521,25 +2549,21 @@ extern "C" int tamd_dev_select(int device)
                     device, prop.gcnArchName);
                 return 1;
         }
-        if (g_device != device) {
-                /* per-device resources are rebuilt lazily */
-                if (g_own_stream) (void)hipStreamDestroy(g_own_stream);
-                g_own_stream = nullptr;
-                if (g_scratch) (void)hipFree(g_scratch);
-                g_scratch = nullptr, g_scratch_size = 0;
-        }
-        g_device = device;
-        g_cus = prop.multiProcessorCount;
-        if (g_own_stream == nullptr)
-                HIP_TRY(hipStreamCreateWithFlags(&g_own_stream, hipStreamNonBlocking));
-        if (g_stream == nullptr) g_stream = g_own_stream;
+        /* what this thread held on its previous device goes (its stream too: a
+         * stream handed in by turtle_amd_stream_set belonged to that device) */
+        g_ctx.release();
+        HIP_TRY(hipSetDevice(device));
+        g_ctx.device = device;
+        g_ctx.cus = prop.multiProcessorCount;
+        HIP_TRY(hipStreamCreateWithFlags(&g_ctx.own_stream, hipStreamNonBlocking));
+        g_ctx.stream = g_ctx.own_stream;
         return 0;
 }
 
 extern "C" int tamd_dev_init(void)
 {
-        if (g_device >= 0) {
-                HIP_TRY(hipSetDevice(g_device));
+        if (g_ctx.device >= 0) {
+                HIP_TRY(hipSetDevice(g_ctx.device)); /* HIP's current device is per thread too */
                 return 0;
         }
         int device = 0;
@@ -2551,20 +2575,39 @@ extern "C" int tamd_dev_init(void)
         return tamd_dev_select(device);
 }
 
-extern "C" int tamd_dev_current(void) { return g_device; }
-extern "C" int tamd_dev_cus(void) { return (tamd_dev_init() == 0) ? g_cus : 0; }
+extern "C" int tamd_dev_current(void) { return g_ctx.device; }
+
+/* what the calling thread holds on its device (a worker calls it before it ends:
+ * nothing is freed behind a thread's back, the runtime may be gone by then) */
+extern "C" void tamd_dev_release(void)
+{
+        g_ctx.release();
+        g_ctx.device = -1;
+}
+extern "C" int tamd_dev_cus(void) { return (tamd_dev_init() == 0) ? g_ctx.cus : 0; }
 
 extern "C" int tamd_dev_stream_set(void * stream)
 {
         if (tamd_dev_init()) return 1;
-        g_stream = (stream != nullptr) ? (hipStream_t)stream : g_own_stream;
+        g_ctx.stream = (stream != nullptr) ? (hipStream_t)stream : g_ctx.own_stream;
         return 0;
 }
 
 extern "C" int tamd_dev_sync(void)
 {
         if (tamd_dev_init()) return 1;
-        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        return 0;
+}
+
+/* every stream of `device` (before memory that other threads' launches may still
+ * read is freed); leaves the calling thread on its own device */
+extern "C" int tamd_dev_sync_device(int device)
+{
+        if (device < 0) return 0;
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipDeviceSynchronize());
+        if (g_ctx.device >= 0) HIP_TRY(hipSetDevice(g_ctx.device));
         return 0;
 }
 
@@ -2581,12 +2624,21 @@ extern "C" void tamd_dev_free(void * ptr)
         if (ptr != nullptr) (void)hipFree(ptr);
 }
 
+/* memory of another device than the calling thread's */
+extern "C" void tamd_dev_free_on(int device, void * ptr)
+{
+        if (ptr == nullptr) return;
+        if ((device >= 0) && (device != g_ctx.device)) (void)hipSetDevice(device);
+        (void)hipFree(ptr);
+        if ((device >= 0) && (device != g_ctx.device) && (g_ctx.device >= 0)) (void)hipSetDevice(g_ctx.device);
+}
+
 extern "C" int tamd_dev_h2d(void * dst, const void * src, size_t bytes)
 {
         if (tamd_dev_init()) return 1;
         if (bytes == 0) return 0;
-        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
         return 0;
 }
 
@@ -2594,41 +2646,63 @@ extern "C" int tamd_dev_d2h(void * dst, const void * src, size_t bytes)
 {
         if (tamd_dev_init()) return 1;
         if (bytes == 0) return 0;
-        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
         return 0;
 }
 
 extern "C" int tamd_dev_zero(void * dst, size_t bytes)
 {
         if (tamd_dev_init()) return 1;
-        HIP_TRY(hipMemsetAsync(dst, 0, bytes, g_stream));
+        HIP_TRY(hipMemsetAsync(dst, 0, bytes, g_ctx.stream));
         return 0;
 }
 
-extern "C" void tamd_scratch_reset(void) { g_scratch_used = 0; }
+extern "C" void tamd_scratch_reset(void) { g_ctx.scratch_used = 0; }
 
 extern "C" int tamd_scratch_get(void ** ptr, size_t bytes)
 {
         *ptr = nullptr;
         if (tamd_dev_init()) return 1;
         const size_t need = (bytes + 255) & ~(size_t)255;
-        if (g_scratch_used + need > g_scratch_size) {
-                if (g_scratch_used != 0) {
+        if (g_ctx.scratch_used + need > g_ctx.scratch_size) {
+                if (g_ctx.scratch_used != 0) {
                         /* pieces already handed out would dangle: the host layer
                          * sizes the arena up front with one oversize request */
                         snprintf(g_error, sizeof(g_error), "scratch arena exhausted");
                         return 1;
                 }
-                HIP_TRY(hipStreamSynchronize(g_stream));
-                if (g_scratch) (void)hipFree(g_scratch);
-                g_scratch = nullptr, g_scratch_size = 0;
+                HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+                if (g_ctx.scratch) (void)hipFree(g_ctx.scratch);
+                g_ctx.scratch = nullptr, g_ctx.scratch_size = 0;
                 const size_t size = need + (need >> 2) + (1u << 20);
-                HIP_TRY(hipMalloc(&g_scratch, size));
-                g_scratch_size = size;
+                HIP_TRY(hipMalloc(&g_ctx.scratch, size));
+                g_ctx.scratch_size = size;
         }
-        *ptr = (char *)g_scratch + g_scratch_used;
-        g_scratch_used += need;
+        *ptr = (char *)g_ctx.scratch + g_ctx.scratch_used;
+        g_ctx.scratch_used += need;
+        return 0;
+}
+
+/* One of the calling thread's grow-only blocks (0: the pager's lists and counters,
+ * 1: the tables of a stack's own batch calls), at least `bytes` long; *grown is
+ * set when it is a new allocation (what it held is gone) */
+extern "C" int tamd_dev_block(int which, void ** ptr, size_t bytes, int * grown)
+{
+        *ptr = nullptr;
+        if (grown != nullptr) *grown = 0;
+        if (tamd_dev_init()) return 1;
+        if (bytes > g_ctx.block_size[which]) {
+                if (g_ctx.block[which] != nullptr) {
+                        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+                        (void)hipFree(g_ctx.block[which]);
+                        g_ctx.block[which] = nullptr, g_ctx.block_size[which] = 0;
+                }
+                HIP_TRY(hipMalloc(&g_ctx.block[which], bytes));
+                g_ctx.block_size[which] = bytes;
+                if (grown != nullptr) *grown = 1;
+        }
+        *ptr = g_ctx.block[which];
         return 0;
 }
 
@@ -2815,8 +2889,8 @@ static int trace_blocks_per_cu(const void * kernel)
         return blocks;
 }
 
-extern "C" void tamd_dev_math_set(int strict) { g_math_strict = strict ? 1 : 0; }
-extern "C" int tamd_dev_math_get(void) { return g_math_strict; }
+extern "C" void tamd_dev_math_set(int strict) { g_ctx.math_strict = strict ? 1 : 0; }
+extern "C" int tamd_dev_math_get(void) { return g_ctx.math_strict; }
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
 static int launch_trace_(struct tamd_view view, long n, bool n_on_device, double * pos,

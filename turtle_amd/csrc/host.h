@@ -51,9 +51,30 @@ struct turtle_map {
         struct turtle_stack * stack; /* owner, or NULL */
 
         uint16_t * nodes;     /* host copy: native endian, rows south->north */
-        void * d_nodes;       /* HBM copy, same layout */
-        int d_stale;          /* host copy changed since the last upload */
+        void * d_nodes[TAMD_MAX_DEVICES]; /* HBM copies (in blocks: internal.h), one per device */
+        unsigned d_fresh;     /* bit d: the copy on device d is current */
 };
+
+/* What threads share -- the HBM copies of a map, the tiles of a stack, the epoch
+ * -- changes under this (recursive) lock.  Launches do not take it: a thread reads
+ * the geometry through tables of its own (its stepper's, or its block 1), built
+ * under the lock from tiles that stay until every stream of the device has
+ * drained (tamd_map_release). */
+void tamd_geometry_lock(void);
+void tamd_geometry_unlock(void);
+unsigned long tamd_geometry_epoch_get(void);
+void tamd_geometry_changed(void);
+/* A thread holds the geometry IN USE from the moment it builds its tables until
+ * the launches that read them are queued (shared with other users; exclusive
+ * against tamd_map_release).  Not held across anything that may free tiles. */
+void tamd_geometry_use_begin(void);
+void tamd_geometry_use_end(void);
+/* ... and whoever may free tiles or maps holds it exclusively, plus the lock */
+void tamd_geometry_write_begin(void);
+void tamd_geometry_write_end(void);
+/* frees the HBM copies of a map (inside write_begin / _end) once what is queued on
+ * their devices has run */
+void tamd_map_release(struct turtle_map * map);
 
 /* fills the decode parameters of `grid` and makes the HBM copy current */
 int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid);
@@ -90,11 +111,6 @@ struct turtle_stack {
         unsigned long * stamp;    /* [lat_n * long_n] when the tile was last wanted */
         unsigned long clock;
         int n_loaded, n_files;
-        /* device tables of the stack's own batch calls (stack.c: stack_view) */
-        void * d_tables;
-        size_t d_tables_size;
-        unsigned long view_epoch;
-        struct tamd_view view;
 };
 
 /* Tiles the stack keeps in memory between calls [ref stack.c:150]: max_size, or
@@ -147,8 +163,10 @@ struct turtle_stepper {
         struct turtle_map * geoid;
         double local_range, slope_factor, resolution_factor;
 
-        /* device tables (rebuilt when the global geometry epoch moves) */
+        /* device tables (rebuilt when the global geometry epoch moves, or the
+         * stepper's thread has moved to another device) */
         unsigned long epoch;
+        int device;                   /* where the tables and the scratch below are (-1: nowhere) */
         void * d_tables;
         size_t d_tables_size;
         struct tamd_view view;
@@ -160,8 +178,8 @@ struct turtle_stepper {
         int last_rounds;              /* rounds the last batch call took (1: nothing was paged in) */
 };
 
-/* Any change to what kernels may read (map nodes, tiles, layers) bumps this. */
-extern unsigned long tamd_geometry_epoch;
+/* Any change to what kernels may read (map nodes, tiles, layers) bumps the epoch
+ * (tamd_geometry_changed). */
 
 /* Builds/refreshes stepper->view; returns an enum turtle_return and a message */
 int tamd_stepper_flatten(struct turtle_stepper * stepper, char * message, size_t size);

@@ -122,8 +122,16 @@ struct tamd_view {
 /* non-zero value after recording a message readable with tamd_dev_error(). */
 /* ------------------------------------------------------------------------ */
 
+/* The device, the stream, the arithmetic mode, the scratch arena and the blocks
+ * below belong to the calling THREAD (device.hip: struct Ctx). */
 const char * tamd_dev_error(void);
-int tamd_dev_init(void);   /* idempotent; selects the device, makes the stream */
+int tamd_dev_init(void);   /* idempotent; selects the thread's device, makes its stream */
+void tamd_dev_release(void); /* frees what the calling thread holds on its device */
+int tamd_dev_sync_device(int device); /* every stream of that device */
+void tamd_dev_free_on(int device, void * ptr);
+/* a grow-only block of the calling thread (0: pager, 1: a stack's own tables) */
+int tamd_dev_block(int which, void ** ptr, size_t bytes, int * grown);
+#define TAMD_MAX_DEVICES 16
 int tamd_dev_count(void);
 int tamd_dev_select(int device);
 int tamd_dev_current(void);

@@ -6,10 +6,68 @@
 #include "host.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
-unsigned long tamd_geometry_epoch = 1;
+/* ---- what threads share (host.h) ------------------------------------------ */
+static pthread_mutex_t g_lock;
+static pthread_rwlock_t g_use = PTHREAD_RWLOCK_INITIALIZER;
+static pthread_once_t g_lock_once = PTHREAD_ONCE_INIT;
+static unsigned long g_epoch = 1;
+
+static void lock_init(void)
+{
+        pthread_mutexattr_t attr;
+        pthread_mutexattr_init(&attr);
+        pthread_mutexattr_settype(&attr, PTHREAD_MUTEX_RECURSIVE);
+        pthread_mutex_init(&g_lock, &attr);
+        pthread_mutexattr_destroy(&attr);
+}
+
+void tamd_geometry_lock(void)
+{
+        pthread_once(&g_lock_once, lock_init);
+        pthread_mutex_lock(&g_lock);
+}
+
+void tamd_geometry_unlock(void) { pthread_mutex_unlock(&g_lock); }
+unsigned long tamd_geometry_epoch_get(void) { return __atomic_load_n(&g_epoch, __ATOMIC_ACQUIRE); }
+void tamd_geometry_changed(void) { __atomic_add_fetch(&g_epoch, 1, __ATOMIC_ACQ_REL); }
+
+void tamd_geometry_use_begin(void) { pthread_rwlock_rdlock(&g_use); }
+void tamd_geometry_use_end(void) { pthread_rwlock_unlock(&g_use); }
+
+/* Whoever may FREE HBM copies holds the geometry exclusively: first against its
+ * users (no thread between building its tables and queueing its launches), then
+ * the lock (always in that order; nested in one thread: the outermost counts). */
+static __thread int t_write_depth = 0;
+
+void tamd_geometry_write_begin(void)
+{
+        if (t_write_depth++ == 0) pthread_rwlock_wrlock(&g_use);
+        tamd_geometry_lock();
+}
+
+void tamd_geometry_write_end(void)
+{
+        tamd_geometry_unlock();
+        if (--t_write_depth == 0) pthread_rwlock_unlock(&g_use);
+}
+
+/* The HBM copies of a map go (inside tamd_geometry_write_begin / _end) once what
+ * is queued on any stream of their devices has run. */
+void tamd_map_release(struct turtle_map * m)
+{
+        int d;
+        for (d = 0; d < TAMD_MAX_DEVICES; d++) {
+                if (m->d_nodes[d] == NULL) continue;
+                tamd_dev_sync_device(d);
+                tamd_dev_free_on(d, m->d_nodes[d]);
+                m->d_nodes[d] = NULL;
+        }
+        m->d_fresh = 0;
+}
 
 /* [ref map.c:54-99] */
 enum turtle_return turtle_map_create(struct turtle_map ** map,
@@ -43,7 +101,6 @@ enum turtle_return turtle_map_create(struct turtle_map ** map,
         m->dz = (info->z[1] - info->z[0]) / 65535;
         strcpy(m->encoding, "none");
         m->projection = proj;
-        m->d_stale = 1;
         *map = m;
         return TURTLE_RETURN_SUCCESS;
 }
@@ -53,6 +110,7 @@ void turtle_map_destroy(struct turtle_map ** map)
 {
         if ((map == NULL) || (*map == NULL)) return;
         struct turtle_map * m = *map;
+        tamd_geometry_write_begin();
         if (m->stack != NULL) { /* a tile leaves its stack */
                 struct turtle_stack * s = m->stack;
                 const int n = s->latitude_n * s->longitude_n;
@@ -64,11 +122,9 @@ void turtle_map_destroy(struct turtle_map ** map)
                         }
                 }
         }
-        if (m->d_nodes != NULL) {
-                tamd_dev_sync(); /* no kernel may still be reading it */
-                tamd_dev_free(m->d_nodes);
-        }
-        tamd_geometry_epoch++;
+        tamd_map_release(m);
+        tamd_geometry_changed();
+        tamd_geometry_write_end();
         free(m->nodes);
         free(m);
         *map = NULL;
@@ -149,7 +205,6 @@ enum turtle_return tamd_map_load_(struct turtle_map ** map, const char * path,
                 if (rc == TURTLE_RETURN_BAD_FORMAT + 100) rc = TURTLE_RETURN_BAD_FORMAT;
                 return tamd_raise_(error, (enum turtle_return)rc, file, line, text, path);
         }
-        m->d_stale = 1;
         *map = m;
         return TURTLE_RETURN_SUCCESS;
 }
@@ -186,9 +241,11 @@ enum turtle_return turtle_map_fill(
                 code = (uint16_t)(int16_t)elevation;
         else
                 code = (uint16_t)round((elevation - map->z0) / map->dz);
+        tamd_geometry_lock();
         map->nodes[(size_t)iy * map->nx + ix] = code;
-        map->d_stale = 1;
-        tamd_geometry_epoch++;
+        map->d_fresh = 0; /* every HBM copy is stale */
+        tamd_geometry_changed();
+        tamd_geometry_unlock();
         return TURTLE_RETURN_SUCCESS;
 }
 
@@ -241,17 +298,28 @@ void turtle_map_meta(const struct turtle_map * map, struct turtle_map_info * inf
 
 int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
 {
-        /* HBM layout: blocks of TAMD_BLOCK x TAMD_BLOCK nodes (internal.h) */
+        /* HBM layout: blocks of TAMD_BLOCK x TAMD_BLOCK nodes (internal.h); one copy
+         * per device, made when a thread on that device first needs it */
+        if (tamd_dev_init()) return 1;
+        const int device = tamd_dev_current();
+        if ((device < 0) || (device >= TAMD_MAX_DEVICES)) return 1;
         const size_t nbx = ((size_t)map->nx + TAMD_BLOCK - 1) / TAMD_BLOCK;
         const size_t nby = ((size_t)map->ny + TAMD_BLOCK - 1) / TAMD_BLOCK;
         const size_t bytes = nbx * nby * TAMD_BLOCK * TAMD_BLOCK * sizeof(*map->nodes);
-        if (map->d_nodes == NULL) {
-                if (tamd_dev_malloc(&map->d_nodes, bytes)) return 1;
-                map->d_stale = 1;
+        tamd_geometry_lock();
+        if (map->d_nodes[device] == NULL) {
+                if (tamd_dev_malloc(&map->d_nodes[device], bytes)) {
+                        tamd_geometry_unlock();
+                        return 1;
+                }
+                map->d_fresh &= ~(1u << device);
         }
-        if (map->d_stale) {
+        if (!(map->d_fresh & (1u << device))) {
                 uint16_t * blocked = calloc(1, bytes);
-                if (blocked == NULL) return 1;
+                if (blocked == NULL) {
+                        tamd_geometry_unlock();
+                        return 1;
+                }
                 int ix, iy;
                 for (iy = 0; iy < map->ny; iy++) {
                         const uint16_t * row = map->nodes + (size_t)iy * map->nx;
@@ -260,13 +328,20 @@ int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
                         for (ix = 0; ix < map->nx; ix++)
                                 to[(size_t)(ix / TAMD_BLOCK) * (TAMD_BLOCK * TAMD_BLOCK) + ix % TAMD_BLOCK] = row[ix];
                 }
-                const int failed = tamd_dev_h2d(map->d_nodes, blocked, bytes);
+                /* (a copy being rewritten while launches of other threads read it:
+                 * turtle_map_fill on a map in use is the caller's race, as in the
+                 * reference) */
+                const int failed = tamd_dev_h2d(map->d_nodes[device], blocked, bytes);
                 free(blocked);
-                if (failed) return 1;
-                map->d_stale = 0;
+                if (failed) {
+                        tamd_geometry_unlock();
+                        return 1;
+                }
+                map->d_fresh |= 1u << device;
         }
+        tamd_geometry_unlock();
         if (grid != NULL) {
-                grid->nodes = map->d_nodes;
+                grid->nodes = map->d_nodes[device];
                 grid->nx = map->nx, grid->ny = map->ny;
                 grid->x0 = map->x0, grid->y0 = map->y0;
                 grid->dx = map->dx, grid->dy = map->dy;

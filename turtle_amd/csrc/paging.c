@@ -14,15 +14,13 @@
  *
  * This file owns the round bookkeeping: the two lists (one being read while
  * the next is written), their counters and the bitmap, all in one grow-only
- * device block.
+ * device block of the calling thread.
  */
 #include <stdlib.h>
 #include <string.h>
 
 #include "host.h"
 
-static void * g_block = NULL;
-static size_t g_block_size = 0;
 
 int tamd_pager_begin(struct tamd_pager * pager, long n, int table_entries)
 {
@@ -33,16 +31,9 @@ int tamd_pager_begin(struct tamd_pager * pager, long n, int table_entries)
         const size_t counters = ((((size_t)table_entries + 1) * sizeof(unsigned) + 255) / 256) * 256;
         const size_t bitmap = ((((size_t)table_entries + 31) / 32 + 1) * sizeof(unsigned) + 255) / 256 * 256;
         const size_t bytes = 2 * list + 256 + counters + bitmap;
-        if (bytes > g_block_size) {
-                if (g_block != NULL) {
-                        tamd_dev_sync();
-                        tamd_dev_free(g_block);
-                        g_block = NULL, g_block_size = 0;
-                }
-                if (tamd_dev_malloc(&g_block, bytes)) return -1;
-                g_block_size = bytes;
-        }
-        char * base = g_block;
+        void * block;
+        if (tamd_dev_block(0, &block, bytes, NULL)) return -1; /* the calling thread's */
+        char * base = block;
         pager->d_list[0] = (int *)base;
         pager->d_list[1] = (int *)(base + list);
         pager->d_count = (unsigned long long *)(base + 2 * list); /* [0], [16]: a line apart */

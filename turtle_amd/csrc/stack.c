@@ -162,6 +162,7 @@ static void stack_release_tiles(struct turtle_stack * s)
 {
         const int n = s->latitude_n * s->longitude_n;
         int i;
+        tamd_geometry_write_begin();
         for (i = 0; i < n; i++) {
                 if (s->tile[i] == NULL) continue;
                 struct turtle_map * m = s->tile[i];
@@ -170,7 +171,8 @@ static void stack_release_tiles(struct turtle_stack * s)
                 s->tile[i] = NULL;
         }
         s->n_loaded = 0;
-        tamd_geometry_epoch++;
+        tamd_geometry_changed();
+        tamd_geometry_write_end();
 }
 
 /* [ref stack.c:228-237] */
@@ -183,7 +185,6 @@ void turtle_stack_destroy(struct turtle_stack ** stack)
         int i;
         for (i = 0; i < n; i++) free(s->path[i]);
         free(s->path), free(s->tile), free(s->stamp), free(s->root);
-        tamd_dev_free(s->d_tables);
         free(s);
         *stack = NULL;
 }
@@ -218,6 +219,7 @@ void tamd_stack_trim(struct turtle_stack * s)
         const int n = s->latitude_n * s->longitude_n, budget = tamd_stack_budget(s);
         if (s->n_loaded <= budget) return;
         if (s->lock != NULL) (void)s->lock();
+        tamd_geometry_write_begin();
         while (s->n_loaded > budget) {
                 int i, out = -1;
                 for (i = 0; i < n; i++) {
@@ -230,8 +232,9 @@ void tamd_stack_trim(struct turtle_stack * s)
                 turtle_map_destroy(&m);
                 s->tile[out] = NULL;
                 s->n_loaded--;
-                tamd_geometry_epoch++;
+                tamd_geometry_changed();
         }
+        tamd_geometry_write_end();
         if (s->unlock != NULL) (void)s->unlock();
 }
 
@@ -256,11 +259,10 @@ static int stack_load_tile(struct turtle_stack * s, int i, char * message, size_
                 return rc;
         }
         m->stack = s;
-        m->d_stale = 1;
         s->tile[i] = m;
         s->stamp[i] = ++s->clock;
         s->n_loaded++;
-        tamd_geometry_epoch++;
+        tamd_geometry_changed();
         return TURTLE_RETURN_SUCCESS;
 }
 
@@ -271,19 +273,20 @@ static void stack_drop_tile(struct turtle_stack * s, int i)
         turtle_map_destroy(&m);
         s->tile[i] = NULL;
         s->n_loaded--;
-        tamd_geometry_epoch++;
+        tamd_geometry_changed();
 }
 
 int tamd_stack_preload(struct turtle_stack * s, char * message, size_t size)
 {
         const int n = s->latitude_n * s->longitude_n, budget = tamd_stack_budget(s);
-        int i;
-        for (i = 0; (i < n) && (s->n_loaded < budget); i++) {
+        int i, rc = TURTLE_RETURN_SUCCESS;
+        tamd_geometry_lock();
+        for (i = 0; (i < n) && (s->n_loaded < budget) && (rc == TURTLE_RETURN_SUCCESS); i++) {
                 if ((s->path[i] == NULL) || (s->tile[i] != NULL)) continue;
-                const int rc = stack_load_tile(s, i, message, size);
-                if (rc != TURTLE_RETURN_SUCCESS) return rc;
+                rc = stack_load_tile(s, i, message, size);
         }
-        return TURTLE_RETURN_SUCCESS;
+        tamd_geometry_unlock();
+        return rc;
 }
 
 static int stack_page_in(struct turtle_stack * s, const unsigned * wanted,
@@ -298,7 +301,9 @@ int tamd_stack_page_in(struct turtle_stack * s, const unsigned * wanted,
                 snprintf(message, size, "could not acquire the lock");
                 return -TURTLE_RETURN_LOCK_ERROR;
         }
+        tamd_geometry_write_begin();
         int rc = stack_page_in(s, wanted, wanted_first, first_bit, message, size);
+        tamd_geometry_write_end();
         if ((s->unlock != NULL) && (s->unlock() != 0) && (rc >= 0)) {
                 snprintf(message, size, "could not release the lock");
                 rc = -TURTLE_RETURN_UNLOCK_ERROR;
@@ -372,21 +377,38 @@ enum turtle_return turtle_stack_load(struct turtle_stack * stack)
         return TURTLE_RETURN_SUCCESS;
 }
 
-/* One-stack view for the elevation / gradient kernels, in a device block the
- * stack keeps (rebuilt when tiles came or went).  Returns 0, -1 on a device
- * error, or a positive enum turtle_return with `message` set. */
+/* One-stack view for the elevation / gradient kernels, in a device block of the
+ * calling THREAD (rebuilt when tiles came or went, or the thread last built
+ * another stack's).  Returns 0, -1 on a device error, or a positive enum
+ * turtle_return with `message` set. */
+static __thread struct {
+        const struct turtle_stack * stack;
+        unsigned long epoch;
+        int device;
+        struct tamd_view view;
+} t_view = { NULL, 0, -1, { 0 } };
+
 static int stack_view(struct turtle_stack * s, struct tamd_view * view, char * message,
     size_t size)
 {
-        if ((s->d_tables != NULL) && (s->view_epoch == tamd_geometry_epoch)) {
-                *view = s->view;
-                return 0;
-        }
+        if (tamd_dev_init()) return -1;
         const int slots = s->latitude_n * s->longitude_n;
         const size_t bytes = sizeof(struct tamd_stack) + sizeof(struct tamd_meta) +
             (size_t)(slots + 1) * (sizeof(int) + sizeof(struct tamd_grid));
+        void * block;
+        int grown = 0;
+        if (tamd_dev_block(1, &block, bytes, &grown)) return -1;
+        tamd_geometry_lock();
+        if (!grown && (t_view.stack == s) && (t_view.epoch == tamd_geometry_epoch_get()) &&
+            (t_view.device == tamd_dev_current())) {
+                *view = t_view.view;
+                tamd_geometry_unlock();
+                return 0;
+        }
+        t_view.stack = NULL;
         char * host = calloc(1, bytes);
         if (host == NULL) {
+                tamd_geometry_unlock();
                 snprintf(message, size, "could not allocate memory");
                 return TURTLE_RETURN_MEMORY_ERROR;
         }
@@ -399,41 +421,34 @@ static int stack_view(struct turtle_stack * s, struct tamd_view * view, char * m
                 tiles[i] = (s->path[i] != NULL) ? TAMD_TILE_PAGED : TAMD_TILE_NONE;
                 if (s->tile[i] == NULL) continue;
                 if (tamd_map_sync(s->tile[i], &grids[n_grids])) {
+                        tamd_geometry_unlock();
                         free(host);
                         return -1;
                 }
                 tiles[i] = n_grids++;
         }
+        const unsigned long epoch = tamd_geometry_epoch_get();
+        tamd_geometry_unlock();
         st->lat0 = s->latitude_0, st->lon0 = s->longitude_0;
         st->dlat = s->latitude_delta, st->dlon = s->longitude_delta;
         st->inv_dlat = 1. / st->dlat, st->inv_dlon = 1. / st->dlon;
         st->nlat = s->latitude_n, st->nlon = s->longitude_n;
         st->tile_first = 0;
         meta->kind = TAMD_STACK;
-        if (bytes > s->d_tables_size) {
-                tamd_dev_sync();
-                tamd_dev_free(s->d_tables);
-                s->d_tables = NULL, s->d_tables_size = 0;
-                if (tamd_dev_malloc(&s->d_tables, bytes)) {
-                        free(host);
-                        return -1;
-                }
-                s->d_tables_size = bytes;
-        }
-        if (tamd_dev_h2d(s->d_tables, host, bytes)) {
+        if (tamd_dev_h2d(block, host, bytes)) {
                 free(host);
                 return -1;
         }
-        char * dev = s->d_tables;
-        memset(&s->view, 0, sizeof(s->view));
-        s->view.grids = (const struct tamd_grid *)dev;
-        s->view.stacks = (const struct tamd_stack *)(dev + ((char *)st - host));
-        s->view.metas = (const struct tamd_meta *)(dev + ((char *)meta - host));
-        s->view.tiles = (const int *)(dev + ((char *)tiles - host));
-        s->view.n_layers = 1;
-        s->view.geoid = -1;
-        s->view_epoch = tamd_geometry_epoch;
-        *view = s->view;
+        char * dev = block;
+        memset(&t_view.view, 0, sizeof(t_view.view));
+        t_view.view.grids = (const struct tamd_grid *)dev;
+        t_view.view.stacks = (const struct tamd_stack *)(dev + ((char *)st - host));
+        t_view.view.metas = (const struct tamd_meta *)(dev + ((char *)meta - host));
+        t_view.view.tiles = (const int *)(dev + ((char *)tiles - host));
+        t_view.view.n_layers = 1;
+        t_view.view.geoid = -1;
+        t_view.stack = s, t_view.epoch = epoch, t_view.device = tamd_dev_current();
+        *view = t_view.view;
         free(host);
         return 0;
 }
@@ -459,17 +474,16 @@ static int stack_rounds(struct stack_call * call, char * message, size_t size)
         for (;;) {
                 struct tamd_view view;
                 struct tamd_paging pg;
-                if ((rc = stack_view(s, &view, message, size)) != 0) break;
-                if (tamd_pager_round(&pager, &pg)) {
-                        rc = -1;
-                        break;
+                tamd_geometry_use_begin();
+                if ((rc = stack_view(s, &view, message, size)) == 0) {
+                        if (tamd_pager_round(&pager, &pg) ||
+                            (call->gradient ?
+                                    tamd_k_gradient(view, call->n, call->a, call->b, call->c, call->d, call->e, pg) :
+                                    tamd_k_elevation(view, call->n, call->a, call->b, call->c, call->e, pg)))
+                                rc = -1;
                 }
-                if (call->gradient ?
-                        tamd_k_gradient(view, call->n, call->a, call->b, call->c, call->d, call->e, pg) :
-                        tamd_k_elevation(view, call->n, call->a, call->b, call->c, call->e, pg)) {
-                        rc = -1;
-                        break;
-                }
+                tamd_geometry_use_end();
+                if (rc != 0) break;
                 unsigned long long faulted = 0;
                 if (tamd_pager_collect(&pager, &faulted)) {
                         rc = -1;

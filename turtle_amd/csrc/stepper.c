@@ -16,6 +16,18 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* what the stepper holds in HBM, on the device it was last used on */
+static void stepper_release_device(struct turtle_stepper * s)
+{
+        if ((s->d_tables != NULL) || (s->d_stats != NULL) || (s->d_parked != NULL))
+                tamd_dev_sync_device(s->device);
+        tamd_dev_free_on(s->device, s->d_tables);
+        tamd_dev_free_on(s->device, s->d_stats);
+        tamd_dev_free_on(s->device, s->d_parked);
+        s->d_tables = NULL, s->d_stats = NULL, s->d_parked = NULL, s->d_scratch_ds = NULL;
+        s->d_tables_size = 0, s->parked_capacity = 0, s->epoch = 0;
+}
+
 /* ---- construction [ref stepper.c:547-600] -------------------------------- */
 
 enum turtle_return turtle_stepper_create(struct turtle_stepper ** stepper)
@@ -24,6 +36,7 @@ enum turtle_return turtle_stepper_create(struct turtle_stepper ** stepper)
         struct turtle_stepper * s = calloc(1, sizeof(*s));
         if (s == NULL)
                 return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
+        s->device = -1;
         s->local_range = 1.; /* defaults [ref stepper.c:558-560] */
         s->slope_factor = 0.4;
         s->resolution_factor = 1E-02;
@@ -39,11 +52,7 @@ enum turtle_return turtle_stepper_destroy(struct turtle_stepper ** stepper)
         for (i = 0; i < s->n_data; i++) /* owned clients [ref stepper.c:578-586] */
                 if (s->data[i].client != NULL) turtle_client_destroy(&s->data[i].client);
         for (i = 0; i < s->n_layers; i++) free(s->layers[i].meta);
-        if ((s->d_tables != NULL) || (s->d_stats != NULL) || (s->d_parked != NULL))
-                tamd_dev_sync();
-        tamd_dev_free(s->d_tables);
-        tamd_dev_free(s->d_stats);
-        tamd_dev_free(s->d_parked);
+        stepper_release_device(s);
         free(s->data);
         free(s->layers);
         free(s);
@@ -62,7 +71,7 @@ static int push_layer(struct turtle_stepper * s)
                 s->layers = l, s->cap_layers = cap;
         }
         memset(&s->layers[s->n_layers++], 0, sizeof(*s->layers));
-        tamd_geometry_epoch++;
+        tamd_geometry_changed();
         return 0;
 }
 
@@ -101,7 +110,7 @@ static int push_meta(struct turtle_stepper * s, int data, double offset)
         l->meta[l->size].data = data;
         l->meta[l->size].offset = offset;
         l->size++;
-        tamd_geometry_epoch++;
+        tamd_geometry_changed();
         return 0;
 }
 
@@ -172,7 +181,7 @@ enum turtle_return turtle_stepper_add_flat(struct turtle_stepper * stepper, doub
 void turtle_stepper_geoid_set(struct turtle_stepper * stepper, struct turtle_map * geoid)
 {
         stepper->geoid = geoid;
-        tamd_geometry_epoch++;
+        tamd_geometry_changed();
 }
 
 struct turtle_map * turtle_stepper_geoid_get(const struct turtle_stepper * stepper)
@@ -235,11 +244,17 @@ static int grid_index(struct grid_list * g, struct turtle_map * m)
         return g->n++;
 }
 
+static int stepper_flatten_locked(struct turtle_stepper * s, char * message, size_t size);
+
 /* Returns 0, -1 for a device error (tamd_dev_error has the text), or a
  * positive enum turtle_return with `message` filled in. */
 int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
 {
         if (tamd_dev_init()) return -1;
+        if (s->device != tamd_dev_current()) { /* the stepper's thread moved to another device */
+                stepper_release_device(s);
+                s->device = tamd_dev_current();
+        }
         if (s->d_stats == NULL) {
                 const size_t words = 4 + TAMD_TRACE_COUNTERS;
                 if (tamd_dev_malloc((void **)&s->d_stats, words * sizeof(*s->d_stats))) return -1;
@@ -247,7 +262,17 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
         }
         s->view.slope = s->slope_factor;
         s->view.resolution = s->resolution_factor;
-        if ((s->epoch == tamd_geometry_epoch) && (s->d_tables != NULL)) return 0;
+        if ((s->epoch == tamd_geometry_epoch_get()) && (s->d_tables != NULL)) return 0;
+        /* the lists of tiles are read, and maps uploaded, under the lock */
+        tamd_geometry_lock();
+        const int rc_ = stepper_flatten_locked(s, message, size);
+        tamd_geometry_unlock();
+        return rc_;
+}
+
+static int stepper_flatten_locked(struct turtle_stepper * s, char * message, size_t size)
+{
+        const unsigned long epoch_now = tamd_geometry_epoch_get();
 
         /* the tiles that are in memory go into the tables; the others read
          * TAMD_TILE_PAGED there and come in when a batch wants them (paging.c) */
@@ -402,7 +427,7 @@ int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
                                 s->view.mode = TAMD_MODE_ONE_MAP;
                         if (h_metas[0].kind == TAMD_STACK) s->view.mode = TAMD_MODE_ONE_STACK;
                 }
-                s->epoch = tamd_geometry_epoch;
+                s->epoch = epoch_now;
         }
         free(host), free(gl.map), free(data_src), free(tiles), free(stacks);
         return dev_fail ? -1 : 0;
@@ -456,14 +481,17 @@ static int stepper_rounds(struct turtle_stepper * stepper, long n, stepper_round
                 return TURTLE_RETURN_LIBRARY_ERROR;
         for (;;) {
                 struct tamd_paging pg;
+                /* tables and launches of a round: nothing they point at may go meanwhile */
+                tamd_geometry_use_begin();
                 rc = tamd_stepper_flatten(stepper, message, size);
-                if (rc != 0) {
+                if (rc != 0)
                         rc = (rc < 0) ? TURTLE_RETURN_LIBRARY_ERROR : rc;
-                        break;
-                }
+                else if (tamd_pager_round(&pager, &pg) || launch(stepper, pg, pager.rounds, args))
+                        rc = TURTLE_RETURN_LIBRARY_ERROR;
+                tamd_geometry_use_end();
+                if (rc != 0) break;
                 unsigned long long faulted = 0;
-                if (tamd_pager_round(&pager, &pg) || launch(stepper, pg, pager.rounds, args) ||
-                    tamd_pager_collect(&pager, &faulted)) {
+                if (tamd_pager_collect(&pager, &faulted)) {
                         rc = TURTLE_RETURN_LIBRARY_ERROR;
                         break;
                 }
@@ -724,9 +752,14 @@ enum turtle_return turtle_stepper_scatter_n(struct turtle_stepper * stepper, lon
                 by_steps = ((env != NULL) && (strcmp(env, "steps") == 0)) ? 1 : 0;
         }
         if ((rc == 0) && !by_steps && !stepper_is_paged(stepper) && (n_steps > 0)) {
-                if (tamd_k_walk(stepper->view, n, a.pos, a.alt, a.elev, a.index, seed, first_ray,
-                        first_step, n_steps, a.length, a.steps, stepper->d_stats, stepper->d_stats + 4))
+                tamd_geometry_use_begin();
+                rc = tamd_stepper_flatten(stepper, message, sizeof(message));
+                if (rc < 0) rc = TURTLE_RETURN_LIBRARY_ERROR;
+                if ((rc == 0) && tamd_k_walk(stepper->view, n, a.pos, a.alt, a.elev, a.index, seed,
+                        first_ray, first_step, n_steps, a.length, a.steps, stepper->d_stats,
+                        stepper->d_stats + 4))
                         rc = TURTLE_RETURN_LIBRARY_ERROR;
+                tamd_geometry_use_end();
                 n_steps = 0;
         }
         for (k = 0; (rc == 0) && (k < n_steps); k++) {
