@@ -3033,6 +3033,15 @@ extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
     unsigned long long * queue)
 {
         if (tamd_dev_init()) return 1;
+        if ((pos == nullptr) || (dir == nullptr) || (index == nullptr) || (stats == nullptr) ||
+            (queue == nullptr) ||
+            ((pg.faulted != nullptr) &&
+                ((pg.tentative == nullptr) || (length == nullptr) || (n_steps == nullptr) ||
+                    (pg.n_faulted == nullptr) || (pg.wanted == nullptr) || (pg.wanted_first == nullptr)))) {
+                /* (a kernel that writes through a null pointer can take the node down) */
+                snprintf(g_error, sizeof(g_error), "tamd_k_trace: a required array is missing");
+                return 1;
+        }
         if (pg.ids == nullptr) HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
         HIP_TRY(hipMemsetAsync(queue, 0, 5 * sizeof(ull), g_stream));
         if (n <= 0) return 0;

@@ -28,6 +28,19 @@ static void stepper_release_device(struct turtle_stepper * s)
         s->d_tables_size = 0, s->parked_capacity = 0, s->epoch = 0;
 }
 
+/* The stepper's HBM (tables, counters, scratch) is on the device of the thread
+ * that uses it: what it held elsewhere goes when that thread has moved on.
+ * Before anything of it is allocated or used. */
+static int stepper_bind_device(struct turtle_stepper * s)
+{
+        if (tamd_dev_init()) return 1;
+        if (s->device != tamd_dev_current()) {
+                if (s->device >= 0) stepper_release_device(s);
+                s->device = tamd_dev_current();
+        }
+        return 0;
+}
+
 /* ---- construction [ref stepper.c:547-600] -------------------------------- */
 
 enum turtle_return turtle_stepper_create(struct turtle_stepper ** stepper)
@@ -250,11 +263,7 @@ static int stepper_flatten_locked(struct turtle_stepper * s, char * message, siz
  * positive enum turtle_return with `message` filled in. */
 int tamd_stepper_flatten(struct turtle_stepper * s, char * message, size_t size)
 {
-        if (tamd_dev_init()) return -1;
-        if (s->device != tamd_dev_current()) { /* the stepper's thread moved to another device */
-                stepper_release_device(s);
-                s->device = tamd_dev_current();
-        }
+        if (stepper_bind_device(s)) return -1;
         if (s->d_stats == NULL) {
                 const size_t words = 4 + TAMD_TRACE_COUNTERS;
                 if (tamd_dev_malloc((void **)&s->d_stats, words * sizeof(*s->d_stats))) return -1;
@@ -581,6 +590,10 @@ enum turtle_return turtle_stepper_position_n(struct turtle_stepper * stepper, lo
 static int tamd_stepper_scratch(struct turtle_stepper * stepper, long n)
 {
         if (n >= 2147483647L) return 1;
+        if (stepper_bind_device(stepper)) {
+                stepper->parked_capacity = -1;
+                return 1;
+        }
         if (n <= stepper->parked_capacity) return 0;
         if (stepper->d_parked != NULL) {
                 tamd_dev_sync();
