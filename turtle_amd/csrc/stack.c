@@ -240,7 +240,14 @@ void tamd_stack_trim(struct turtle_stack * s)
 
 int turtle_amd_stack_resident(const struct turtle_stack * stack) { return stack->n_loaded; }
 
-int tamd_stack_is_paged(const struct turtle_stack * s) { return s->n_loaded < s->n_files; }
+/* Can a lookup meet a tile that has a file and is not in memory?  Now -- or, with
+ * other threads at work on the stack, by the time its kernel runs: a stack that
+ * may not keep all its files can lose a tile to another thread's call at any
+ * moment, so its batches always run with the paging bookkeeping in place. */
+int tamd_stack_is_paged(const struct turtle_stack * s)
+{
+        return (s->n_loaded < s->n_files) || (tamd_stack_budget(s) < s->n_files);
+}
 
 /* one tile from its file into memory (it goes on to HBM at the next device call) */
 static int stack_load_tile(struct turtle_stack * s, int i, char * message, size_t size)
