@@ -10,6 +10,8 @@ Bar (BASELINE.json north_star): identical medium index, path length within
 is bit-exact.  Transcendentals come from OCML instead of glibc, so floating
 outputs may differ in the last ulp: tolerances are written at each assert.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -796,3 +798,49 @@ def test_plain_c_caller(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(out.stdout[-600:], out.stderr[-300:])
     assert out.returncode == 0 and "0 disagreements" in out.stdout
+
+
+def test_c_host_with_threads_and_rccl(tmp_path):
+    """examples/multi_gpu_tally.c: a C host, one thread per GPU over a shared map,
+    the tally reduced with ncclAllReduce(ncclUint64) over RCCL; on this one-GPU box
+    it runs with one rank (communicator of one) and checks its own sums."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(tmp_path, "multi_gpu_tally")
+    lib = os.path.join(root, "turtle_amd")
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-D__HIP_PLATFORM_AMD__",
+                           "-I" + os.path.join(root, "include"), "-I/opt/rocm/include",
+                           os.path.join(root, "examples", "multi_gpu_tally.c"), "-L" + lib,
+                           "-lturtle_amd", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-lpthread", "-lm",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe, "1", "100000"], capture_output=True, text=True, timeout=300)
+    print(out.stdout[-400:], out.stderr[-400:])
+    assert out.returncode == 0 and "reduced tally == one-GPU tally" in out.stdout
+
+
+def test_two_ranks_share_the_gpu_through_bench(tmp_path):
+    """The N > 1 path of bench.py itself on this one-GPU box: two ranks over gloo
+    (RCCL needs a GPU per rank) trace their blocks and all-reduce the tally; one
+    rank tracing both blocks (--blocks 2) gets the same tally, to the bit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--rays", "150000", "--steps", "2", "--warmup", "1", "--no-cpu", "--workload", "c2",
+              "--also", "none"]
+    env = dict(os.environ, TURTLE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+                          os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--blocks", "2"]
+                         + common, capture_output=True, text=True, timeout=600, cwd=root)
+    lines = []
+    for out in (two, one):
+        rows = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert out.returncode == 0 and len(rows) == 1, (out.stdout[-500:], out.stderr[-1500:])
+        lines.append(json.loads(rows[0]))
+    assert lines[0]["n_gpus"] == 2 and lines[1]["n_gpus"] == 1
+    assert lines[0]["tally"] == lines[1]["tally"]
+    assert sum(lines[0]["tally"]["hits"]) == 300000
+    assert lines[0]["kernel"]["steps_per_launch"] * 2 > lines[1]["kernel"]["steps_per_launch"] > 0
