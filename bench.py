@@ -43,6 +43,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_CLOCK_HZ = 2.4e9       # MI355X peak engine clock (MI355X_MICROARCH.md)
 TRACE_KERNEL = "k_trace (phase A: all rays up to 512 steps; phase B: what is left, long rays on their lines)"
 STEP_KERNELS = "k_step_fast + k_bisect per generation (single steps, directions drawn in the kernel)"
+WALK_KERNEL = "k_walk (a ray's whole walk in one launch: state in registers, directions drawn in the kernel)"
 SEED = 0x5EED2026
 PARITY_RAYS = 100_000
 
@@ -327,7 +328,10 @@ def run_workload(name, args, env, headline):
     out = None
     if rank == 0:
         value = total_steps_per_pass * steps / elapsed
-        launches = args.scatter_steps if scatter else 1
+        # a walk over resident tiles is ONE launch (k_walk); over paged tiles, or with
+        # TURTLE_AMD_WALK=steps, two kernels per generation
+        by_steps = bool(args.stack_size) or os.environ.get("TURTLE_AMD_WALK") == "steps"
+        launches = (args.scatter_steps if by_steps else 1) if scatter else 1
         if scatter:
             # SURVEY 8d, single-step batch mode: 8 B of nodes per sample + 48 in (pos, dir
             # -- drawn in the kernel here, but the state it stands for) + 24 (pos out) + 8
@@ -335,8 +339,9 @@ def run_workload(name, args, env, headline):
             samples_per_step = stats["samples"] / max(1, stats["steps"])
             alg_bytes = (8.0 * samples_per_step + 88.0) * stats["steps"]
             per_launch = alg_bytes / launches
-            kernel = {"name": STEP_KERNELS, "ms": kernel_ms, "launches_per_step": launches,
-                      "ms_per_generation": kernel_ms / launches,
+            kernel = {"name": STEP_KERNELS if by_steps else WALK_KERNEL, "ms": kernel_ms,
+                      "launches_per_step": launches,
+                      "ms_per_generation": kernel_ms / args.scatter_steps,
                       "steps_per_pass": stats["steps"], "samples_per_pass": stats["samples"],
                       "samples_per_step": samples_per_step,
                       "gpu_steps_per_s": stats["steps"] / (kernel_ms * 1e-3)}
@@ -374,7 +379,9 @@ def run_workload(name, args, env, headline):
                                  "events on the launch stream); traffic = FETCH_SIZE+WRITE_SIZE "
                                  "bytes per launch (PMC, offline, same kernel source: null when "
                                  "the source has changed since).  A trace is fp64-latency shaped, "
-                                 "not bandwidth shaped: see DESIGN.md"},
+                                 "not bandwidth shaped; the algorithmic bytes of a walk are SURVEY's, "
+                                 "which stream the ray state at every step -- k_walk keeps it in "
+                                 "registers, so what it really moves is far less: see DESIGN.md"},
             "tally": {"hits": [int(v) for v in tally[t_hits].tolist()],
                       "sha256": hashlib.sha256(tally.cpu().numpy().tobytes()).hexdigest()[:16]},
         }
