@@ -1495,6 +1495,37 @@ __device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsign
         }
 }
 
+/* sin and cos of 2 pi u, 0 <= u < 1, to the last ulp or so: the quadrant comes off
+ * u exactly (k = round(4 u), r = u - k / 4 in [-1/8, 1/8]: no rounding), the rest is
+ * the classic pair of polynomials on [-pi/4, pi/4] (fdlibm's k_sin / k_cos
+ * coefficients) and a swap / sign by quadrant.  ~30 instructions where OCML's
+ * sin + cos take ~250 with their large-argument paths: the walk kernel draws a
+ * direction per step and is bound by the rate its instructions issue at. */
+__device__ __forceinline__ void d_sincos_2pi(double u, double & s, double & c)
+{
+        const double k = __builtin_rint(4. * u); /* 0 .. 4 */
+        const double t = 6.283185307179586 * __builtin_fma(-0.25, k, u);
+        const double z = t * t;
+        double ps = 1.58969099521155010221e-10;
+        ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+        ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+        ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+        ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+        ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+        const double sn = __builtin_fma(t * z, ps, t);
+        double pc = -1.13596475577881948265e-11;
+        pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+        pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+        pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+        pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+        pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+        const double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.));
+        const int q = (int)k & 3;
+        /* 2 pi u = q pi / 2 + t */
+        s = (q == 0) ? sn : ((q == 1) ? cs : ((q == 2) ? -sn : -cs));
+        c = (q == 0) ? cs : ((q == 1) ? -sn : ((q == 2) ? -cs : sn));
+}
+
 /* the isotropic unit vector of (ray id, stream; seed): see k_isotropic */
 __device__ __forceinline__ void d_isotropic(ull id, ull stream, ull seed, double & x, double & y, double & z)
 {
@@ -1505,8 +1536,9 @@ __device__ __forceinline__ void d_isotropic(ull id, ull stream, ull seed, double
         const double u2 = (double)(((ull)(c[2] >> 5) << 26) | (c[3] >> 6)) * scale;
         const double ct = 2. * u1 - 1.;
         const double st = sqrt(1. - ct * ct);
-        const double phi = 2. * kPi * u2;
-        x = st * cos(phi), y = st * sin(phi), z = ct;
+        double sp, cp;
+        d_sincos_2pi(u2, sp, cp);
+        x = st * cp, y = st * sp, z = ct;
 }
 
 /* Where a batch of single steps takes its directions from: an array, or -- a
