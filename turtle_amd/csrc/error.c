@@ -113,6 +113,7 @@ const char * turtle_error_function(turtle_function_t * caller)
         NAME(turtle_stepper_position_n);
         NAME(turtle_stepper_step_n);
         NAME(turtle_stepper_trace_n);
+        NAME(turtle_stepper_scatter_n);
         NAME(turtle_stepper_trace_stats);
         NAME(turtle_amd_tally_n);
         NAME(turtle_amd_philox_n);
