@@ -1879,17 +1879,6 @@ struct PhaseIO {
                               * line (see LINED) */
         int chunk;           /* rays a wave draws from the queue at once */
         int creep_lanes;     /* the creep loop engages at or below this many live lanes */
-        /* the SORTING pass (run_trace): every ray takes `quantum` steps and goes on one of
-         * two lists by how fast it has been closing in on the ground: `parked` if at that
-         * rate it cannot be down within park_after steps -- clearance(quantum) / clearance(0)
-         * above split -- else `short_list`; the next pass takes the first list, then the
-         * second (ids, then ids2) */
-        int quantum;
-        double split;
-        int * short_list;
-        ull * n_short;
-        const int * ids2;
-        const ull * n_dev2;
 };
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
@@ -1898,8 +1887,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
     int flags, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
 {
-        const long n_first = (ph.n_dev != nullptr) ? (long)*ph.n_dev : n; /* of the list `ids` */
-        if (ph.n_dev != nullptr) n = n_first + ((ph.n_dev2 != nullptr) ? (long)*ph.n_dev2 : 0);
+        if (ph.n_dev != nullptr) n = (long)*ph.n_dev;
         /* MODEL: besides its accumulated position B (bx, by, bz: the reference's
          * roundings, in every phase: see kLineTau0) a ray on its line carries
          * line.s, the path length from the point where the line was laid to B */
@@ -1928,8 +1916,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         double ds = 0, ds0 = 0, ds1 = 0;
         int m = -1, k = -1, bm = -1, bk = -1, halvings = 0;
         int home = -1; /* CAN_FAULT: the tile of the ray's last sample (see Sample.slot) */
-        double h0 = 0.; /* sorting pass: the ray's clearance where it started */
-        bool park_short = false;
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_capped = 0;
 
         for (;;) {
@@ -1961,7 +1947,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                         if (need && (rank < avail)) {
                                 ray = pool_next + rank;
-                                if (ph.ids != nullptr) ray = (ray < n_first) ? ph.ids[ray] : ph.ids2[ray - n_first];
+                                if (ph.ids != nullptr) ray = ph.ids[ray];
                                 if (MODEL) line.valid = false, line.s = 0., line.tau = kLineTau0;
                                 bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
                                 dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
@@ -2181,7 +2167,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         } else if (state == ST_INIT) {
                                 m = s.m, k = s.k;
                                 ds = (m >= 0) ? d_step_length(v, s.alt, s.e0, s.e1, m) : 0.;
-                                if (!MODEL) h0 = fmin(fabs(s.alt - s.e0), fabs(s.alt - s.e1));
                                 if ((flags & TRACE_CARRY_MEDIUM) && (m >= 0)) {
                                         /* The caller knows which medium the ray
                                          * is in; the sample only sizes the step.
@@ -2228,22 +2213,6 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 /* on to the next phase (always at the same step count:
                                  * the line a ray lays there is part of its arithmetic) */
                                 park = accept & !capped & (ph.park_after > 0) & (count >= ph.park_after);
-                                if (!MODEL && (ph.quantum > 0) && accept && !capped && !park &&
-                                    (count - count0 >= ph.quantum)) {
-                                        /* its clearance now against the one it started with: the
-                                         * rate it closes in at, and with it the steps it has left */
-                                        const double h = fmin(fabs(s.alt - s.e0), fabs(s.alt - s.e1));
-                                        /* down to one minimum step's clearance within park_after
-                                         * steps at a constant rate: h(q) / h(0) = (h_min / h(0)) ^
-                                         * (q / park_after) */
-                                        /* (in base-2 logarithms of the hardware's single
-                                         * precision: a sorting key, not a result) */
-                                        const double h_min = v.resolution / v.slope;
-                                        const float lr = __builtin_amdgcn_logf((float)(h / fmax(h0, h_min)));
-                                        const float l0 = __builtin_amdgcn_logf((float)(h_min / fmax(h0, h_min)));
-                                        park = true;
-                                        park_short = !(lr > (float)ph.split * l0);
-                                }
                                 if (MODEL && accept && !capped && !park && !lined_ &&
                                     (count >= ph.line_after)) {
                                         /* phase B: from here on the ray steps on its line,
@@ -2274,24 +2243,17 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         }
                 }
                 /* ---- park over-long rays (phase A; whole wave takes part) ---- */
-                const ull pmask = __ballot(park & !park_short), smask = __ballot(park & park_short);
-                if ((pmask | smask) != 0) {
-                        /* one atomic per list and wave */
-                        ull base = 0, sbase = 0;
-                        if ((threadIdx.x & 63) == 0) {
-                                if (pmask != 0) base = atomicAdd(ph.n_parked, (ull)__popcll(pmask));
-                                if (smask != 0) sbase = atomicAdd(ph.n_short, (ull)__popcll(smask));
-                        }
-                        base = __shfl(base, 0, 64), sbase = __shfl(sbase, 0, 64);
+                const ull pmask = __ballot(park);
+                if (pmask != 0) {
+                        const int leader = __builtin_ctzll(pmask);
+                        ull base = 0;
+                        if ((int)(threadIdx.x & 63) == leader)
+                                base = atomicAdd(ph.n_parked, (ull)__popcll(pmask));
+                        base = __shfl(base, leader, 64);
                         if (park) {
-                                const ull mine = park_short ? smask : pmask;
-                                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32),
-                                    __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
-                                if (park_short)
-                                        ph.short_list[sbase + rank] = (int)ray;
-                                else
-                                        ph.parked[base + rank] = (int)ray;
-                                park_short = false;
+                                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pmask >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((unsigned)pmask, 0));
+                                ph.parked[base + rank] = (int)ray;
                                 pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
                                 index[2 * ray] = m, index[2 * ray + 1] = k;
                                 length[ray] = len;
@@ -3045,32 +3007,19 @@ static int drain_lanes(void)
         return value;
 }
 
-static int sort_steps(void)
-{
-        static int value = -1;
-        if (value < 0) value = max(0, env_int("TURTLE_AMD_SORT_STEPS", 64));
-        return value;
-}
-
 /* One round of a trace: all the rays (pg.ids == NULL), or the ones the last
  * round listed because they needed a tile (they carry on from the arrays).
  *
- * Fast arithmetic runs in phases: A steps everything to 512 steps by the closed
- * form and hands over what is left when its queue runs dry (C2: 260 k of 1 M
- * rays); B takes those to the end, a ray beyond 512 steps on its line.  A ray
+ * Fast arithmetic runs in phases, each with fewer and longer rays than the one
+ * before: A steps everything to 512 steps and hands over what is left when its
+ * queue runs dry (C2: 260 k of 1 M rays); B takes those to the end.  A ray
  * changes phase at fixed step counts, or (below 512 steps) where its arithmetic
- * does not depend on the phase: see LINED.
- *
- * What a launch waits for in the end is a ray that is long AND started late: its
- * 512 closed-form steps are 1.2 ms of dependent arithmetic whatever else runs,
- * then thousands of steps on its line.  A batch several times the lanes of the
- * chip therefore starts with a SORTING pass: every ray takes its first 64 steps
- * and goes on one of two lists by the rate at which it has been closing in on the
- * ground -- at h(64) / h(0) it either can or cannot be down within 512 steps
- * (measured on C2: the slow 40 % hold every ray beyond 512 steps but 2 %) -- and
- * phase A takes the slow list first: the long rays start early, and what it holds
- * when its queue runs dry are rays with a few dozen steps left.  Which list a ray
- * is on changes when it is computed, never what. */
+ * does not depend on the phase: see LINED.  A third phase C for the rays beyond
+ * a second threshold (TURTLE_AMD_PARK2; a few to a wave, on an otherwise empty
+ * chip) is wired in but off: measured on C2, every threshold from 544 to 2 048
+ * made the trace slower (8.5-9.5 ms against 7.5 ms) -- what phase B waits for
+ * is not its one longest ray but the medium ones (1 000-2 500 steps) stepping in
+ * waves that are neither full nor down to a handful of rays. */
 template <int MODE>
 static int run_trace(struct tamd_view view, long n, double * pos, const double * dir,
     int max_steps, int * index, double * length, int * n_steps, int flags, int * parked,
@@ -3079,8 +3028,7 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         const bool again = (pg.ids != nullptr);
         if (again) flags |= TRACE_CARRY_MEDIUM;
         const int resume = again ? 2 : 0;
-        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, resume, pg, 0, 0, kChunk, creep_lanes(n),
-                0, 0., nullptr, nullptr, nullptr, nullptr };
+        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, resume, pg, 0, 0, kChunk, creep_lanes(n) };
         if (g_math_strict || !view.fast_ok)
                 return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
@@ -3089,34 +3037,27 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
             (n_steps == nullptr))
                 return launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
-        /* lists: parked[0 .. n) from A to B, parked[n .. 2n) and [2n .. 3n) the slow and the
-         * fast list of the sorting pass; counters: queue[0], [1], [5]: the work queues of A, B
-         * and the sorting pass; queue[2], [6], [7]: the lengths of the lists */
-        const int quantum = sort_steps();
-        const long in_flight = (long)g_cus * 4 * 4 * 64;
-        const bool sorted = (quantum > 0) && (quantum < park) && (n > 2 * in_flight);
-        PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, resume, pg, drain_lanes(), 0, kChunk,
-                creep_lanes(n), 0, 0., nullptr, nullptr, nullptr, nullptr };
-        if (sorted) {
-                const PhaseIO sort = { pg.ids, pg.n_in, parked + n, queue + 6, park, resume, pg, 0, 0, kChunk,
-                        creep_lanes(n), quantum, (double)quantum / (double)park, parked + 2 * n, queue + 7,
-                        nullptr, nullptr };
-                if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
-                        n_steps, flags, sort, stats, queue + 5))
-                        return 1;
-                a.ids = parked + n, a.n_dev = queue + 6, a.ids2 = parked + 2 * n, a.n_dev2 = queue + 7;
-                a.accumulate = 1;
-        }
-        if (launch_trace<MODE, true, false>(view, n, again || sorted, pos, dir, max_steps, index, length,
-                n_steps, sorted ? (flags | TRACE_CARRY_MEDIUM) : flags, a, stats, queue))
+        /* lists: parked[0 .. n) from A to B, parked[n .. 2n) from B to C; counters:
+         * queue[0], [1], [3]: the work queues of A, B, C; queue[2], [4]: the lists */
+        int park2 = park_threshold_2();
+        if ((park2 <= park) || (max_steps <= park2)) park2 = 0;
+        const PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, resume, pg, drain_lanes(), 0,
+                kChunk, creep_lanes(n) };
+        if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
+                n_steps, flags, a, stats, queue))
                 return 1;
-        const PhaseIO b = { parked, queue + 2, nullptr, nullptr, 0, 1, pg, 0, park, kChunk, creep_lanes(n),
-                0, 0., nullptr, nullptr, nullptr, nullptr };
+        const PhaseIO b = { parked, queue + 2, park2 ? parked + n : nullptr, queue + 4, park2, 1, pg,
+                0, park, kChunk, creep_lanes(n) };
+        if (launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
+                n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1))
+                return 1;
+        if (park2 == 0) return 0;
+        const PhaseIO c = { parked + n, queue + 4, nullptr, nullptr, 0, 1, pg, 0, park, kTailChunk, creep_lanes(n) };
         return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
-            n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1);
+            n_steps, flags | TRACE_CARRY_MEDIUM, c, stats, queue + 3);
 }
 
-/* queue: eight counters (see run_trace); parked: room for 3 n ray ids.  pg: the round of a paged geometry (paging.c), all NULL otherwise; the
+/* queue: five counters (see run_trace); parked: room for 2 n ray ids.  pg: the round of a paged geometry (paging.c), all NULL otherwise; the
  * counters in `stats` add up over the rounds of a call. */
 extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
@@ -3134,7 +3075,7 @@ extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
                 return 1;
         }
         if (pg.ids == nullptr) HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
-        HIP_TRY(hipMemsetAsync(queue, 0, 8 * sizeof(ull), g_stream));
+        HIP_TRY(hipMemsetAsync(queue, 0, 5 * sizeof(ull), g_stream));
         if (n <= 0) return 0;
         const int carry = (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0;
         if (view.mode == TAMD_MODE_ONE_MAP)
