@@ -844,3 +844,42 @@ def test_two_ranks_share_the_gpu_through_bench(tmp_path):
     assert lines[0]["tally"] == lines[1]["tally"]
     assert sum(lines[0]["tally"]["hits"]) == 300000
     assert lines[0]["kernel"]["steps_per_launch"] * 2 > lines[1]["kernel"]["steps_per_launch"] > 0
+
+
+def test_scatter_over_a_stack_against_the_oracle(math, tmp_path):
+    """Config C5 in small, on its real kind of terrain: a walk of 64 generations over a
+    3 x 3 mosaic with a hole (seams, the rim, rays that leave), every step against the
+    CPU restatement's single steps, directions from the library's Philox."""
+    tiles = [(la, lo) for la in (45, 46, 47) for lo in (3, 4, 5) if (la, lo) != (46, 4)]
+    stack = B.mosaic(tmp_path, tiles, 1201)
+    stack.load()
+    geo = T.mosaic_oracle(tiles, 1201, 45, 3, 3, 3)
+    st = TA.Stepper()
+    st.add_stack(stack, 0.0)
+    n, K = 6000, 64
+    lat, lon, _, _ = TA.synth.uniform_rays(n, (45.0, 48.0), (3.0, 6.0), seed=21, margin=0.02)
+    pos, di = st.position(lat, lon, 60.0)
+    pos = pos[di == 0]
+    n = pos.shape[0]
+    w = st.scatter(pos.copy(), 777, K, first_ray=5)
+    ref_pos, total = pos.copy(), np.zeros(n)
+    o = geo.step(ref_pos)
+    alive = o["index"][:, 0] >= 0
+    steps = np.zeros(n, dtype=np.int32)
+    for k in range(K):
+        d = TA.isotropic(n, 777, k, first_ray=5, device=False)
+        o = geo.step(ref_pos, d)
+        ref_pos = np.where(alive[:, None], o["position"], ref_pos)
+        total += np.where(alive, o["step"], 0.0)
+        steps += alive
+        alive &= o["index"][:, 0] >= 0
+    ref_medium = np.where(alive, o["index"][:, 0], -1)
+    same = (w["index"][:, 0] == ref_medium) & (w["steps"] == steps)
+    # a ray that lands on the other side of a surface by 1e-9 m has diverged for good
+    assert (~same).sum() <= 3, int((~same).sum())
+    assert np.abs(w["position"][same] - ref_pos[same]).max() < 1e-5
+    rel = np.abs(w["length"][same] - total[same]) / np.maximum(total[same], 1e-300)
+    assert rel.max() <= REL, rel.max()
+    assert (steps < K).sum() > 20          # rays did leave: through the hole and the rim
+    st.destroy()
+    stack.destroy()
