@@ -858,7 +858,8 @@ def test_scatter_over_a_stack_against_the_oracle(math, tmp_path):
     st.add_stack(stack, 0.0)
     n, K = 6000, 64
     lat, lon, _, _ = TA.synth.uniform_rays(n, (45.0, 48.0), (3.0, 6.0), seed=21, margin=0.02)
-    pos, di = st.position(lat, lon, 60.0)
+    height = np.where(np.arange(n) % 4 == 0, 30000.0, 60.0)   # high ones take 10 km steps: they leave
+    pos, di = st.position(lat, lon, height)
     pos = pos[di == 0]
     n = pos.shape[0]
     w = st.scatter(pos.copy(), 777, K, first_ray=5)
