@@ -9,7 +9,8 @@ until the medium changes (hit or exit).  One "step" of this benchmark = one
 turtle_stepper_trace_n call over the whole batch, inputs resident in HBM.
 
 With no --workload (what the driver runs) the line also carries, under "also",
-one measured pass each of C3 (10 M rays, 4x4 mosaic through a stack) and C5 (10 M
+one measured pass each of C3 (10 M rays, 4x4 mosaic through a stack; and again with
+8 of its 16 tiles resident), C4 (12.5 M rays: one rank of the 8-GPU config) and C5 (10 M
 scattering rays x 256 single steps over a 10x10 mosaic), and every workload
 reports a parity count: the outputs the GPU just produced against the CPU
 restatement (oracle/) on its first 100 000 rays.
@@ -495,7 +496,7 @@ def main():
     head = run_workload(head_name, args, env, headline=True)
     also = args.also
     if also is None:
-        also = "c3,c3@8,c5" if (args.workload is None and world == 1) else "none"
+        also = "c3,c3@8,c4,c5" if (args.workload is None and world == 1) else "none"
     extra = {}
     for name in [w for w in also.split(",") if w and w != "none"]:
         sub = argparse.Namespace(**vars(args))

@@ -2516,6 +2516,8 @@ struct Ctx {
         size_t scratch_size = 0, scratch_used = 0;
         void * block[2] = { nullptr, nullptr }; /* grow-only: the pager's lists, a stack's own tables */
         size_t block_size[2] = { 0, 0 };
+        void * pinned = nullptr; /* host memory the device can copy from / to without staging */
+        size_t pinned_size = 0;
         void release()
         {
                 if (device < 0) return;
@@ -2524,6 +2526,8 @@ struct Ctx {
                 if (scratch != nullptr) (void)hipFree(scratch);
                 for (int i = 0; i < 2; i++)
                         if (block[i] != nullptr) (void)hipFree(block[i]);
+                if (pinned != nullptr) (void)hipHostFree(pinned);
+                pinned = nullptr, pinned_size = 0;
                 own_stream = stream = nullptr, scratch = nullptr, scratch_size = scratch_used = 0;
                 block[0] = block[1] = nullptr, block_size[0] = block_size[1] = 0;
         }
@@ -2687,6 +2691,30 @@ extern "C" int tamd_dev_zero(void * dst, size_t bytes)
 {
         if (tamd_dev_init()) return 1;
         HIP_TRY(hipMemsetAsync(dst, 0, bytes, g_ctx.stream));
+        return 0;
+}
+
+extern "C" int tamd_dev_pinned(void ** ptr, size_t bytes)
+{
+        *ptr = nullptr;
+        if (tamd_dev_init()) return 1;
+        if (bytes > g_ctx.pinned_size) {
+                HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+                if (g_ctx.pinned != nullptr) (void)hipHostFree(g_ctx.pinned);
+                g_ctx.pinned = nullptr, g_ctx.pinned_size = 0;
+                HIP_TRY(hipHostMalloc(&g_ctx.pinned, bytes, hipHostMallocDefault));
+                g_ctx.pinned_size = bytes;
+        }
+        *ptr = g_ctx.pinned;
+        return 0;
+}
+
+extern "C" int tamd_dev_copy_async(void * dst, const void * src, size_t bytes, int to_device)
+{
+        if (tamd_dev_init()) return 1;
+        if (bytes == 0) return 0;
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
+            g_ctx.stream));
         return 0;
 }
 

@@ -203,8 +203,18 @@ void tamd_pager_end(struct tamd_pager * pager);
 #define TAMD_PAGING_ROUNDS 100000 /* a batch needs about one round per tile it touches */
 
 /* ---- HOST/DEVICE array staging for the batch calls ----------------------- */
+#define TAMD_STAGE_PENDING 12
 struct tamd_stage {
         int space;
+        int packed;          /* small HOST call: through the thread's pinned buffer (stage.c) */
+        int n_pending;
+        char * pinned;
+        size_t pinned_used;
+        struct {
+                void * user;
+                const char * pinned;
+                size_t bytes;
+        } pending[TAMD_STAGE_PENDING]; /* outputs on their way back: copied out by tamd_stage_end */
 };
 int tamd_stage_begin(struct tamd_stage * st, int space, size_t total_bytes);
 /* returns the device address to use for a user array (NULL stays NULL) */

@@ -146,6 +146,10 @@ void tamd_dev_free(void * ptr);
 int tamd_dev_h2d(void * dst, const void * src, size_t bytes); /* stream-ordered, then synced */
 int tamd_dev_d2h(void * dst, const void * src, size_t bytes);
 int tamd_dev_zero(void * dst, size_t bytes);                   /* stream-ordered */
+/* a pinned host buffer of the calling thread (grow-only), and copies between it and
+ * HBM that are queued on the thread's stream and not waited for */
+int tamd_dev_pinned(void ** ptr, size_t bytes);
+int tamd_dev_copy_async(void * dst, const void * src, size_t bytes, int to_device);
 
 /* Grow-only scratch arena for HOST-space calls: reset at the start of each
  * API call, handed out in 256-byte aligned pieces. */

@@ -399,6 +399,7 @@ static int map_elevation_n(struct turtle_map * map, long n, const double * x,
             tamd_stage_fetch(&st, inside, n * sizeof(int), di))
                 return 1;
         /* the one-grid tables sit in the scratch arena: finish before reuse */
+        if (tamd_stage_end(&st)) return 1;
         return tamd_dev_sync();
 }
 
@@ -455,6 +456,7 @@ static int map_gradient_n(struct turtle_map * map, long n, const double * x,
         if (tamd_stage_fetch(&st, gx, nb, dgx) || tamd_stage_fetch(&st, gy, nb, dgy) ||
             tamd_stage_fetch(&st, inside, n * sizeof(int), di))
                 return 1;
+        if (tamd_stage_end(&st)) return 1;
         return tamd_dev_sync();
 }
 

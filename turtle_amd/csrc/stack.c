@@ -532,7 +532,7 @@ static int stack_elevation_n(struct turtle_stack * stack, long n,
         if (tamd_stage_fetch(&st, elevation, nb, dz) ||
             tamd_stage_fetch(&st, inside, n * sizeof(int), di))
                 return -1;
-        return tamd_dev_sync() ? -1 : 0;
+        return tamd_stage_end(&st) ? -1 : 0;
 }
 
 enum turtle_return turtle_stack_elevation_n(struct turtle_stack * stack, long n,
@@ -601,7 +601,7 @@ static int stack_gradient_n(struct turtle_stack * stack, long n, const double * 
         if (tamd_stage_fetch(&st, glat, nb, dga) || tamd_stage_fetch(&st, glon, nb, dgb) ||
             tamd_stage_fetch(&st, inside, n * sizeof(int), di))
                 return -1;
-        return tamd_dev_sync() ? -1 : 0;
+        return tamd_stage_end(&st) ? -1 : 0;
 }
 
 enum turtle_return turtle_stack_gradient_n(struct turtle_stack * stack, long n,
