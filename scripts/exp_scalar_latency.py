@@ -30,7 +30,7 @@ for _ in range(n):
     m.elevation_scalar(3.5, 45.5)
 t2 = time.perf_counter()
 for _ in range(n):
-    TA.scalar_ecef_to_geodetic(p)
+    TA.binding.scalar_ecef_to_geodetic(p)
 t3 = time.perf_counter()
 print(f"turtle_stepper_step {1e6 * (t1 - t0) / n:.1f} us, turtle_map_elevation {1e6 * (t2 - t1) / n:.1f} us, "
       f"turtle_ecef_to_geodetic {1e6 * (t3 - t2) / n:.1f} us per call (ctypes overhead included)")

@@ -212,9 +212,9 @@ struct tamd_stage {
         size_t pinned_used;
         struct {
                 void * user;
-                const char * pinned;
+                const void * dev;
                 size_t bytes;
-        } pending[TAMD_STAGE_PENDING]; /* outputs on their way back: copied out by tamd_stage_end */
+        } pending[TAMD_STAGE_PENDING]; /* outputs to bring back: tamd_stage_end does, in one copy */
 };
 int tamd_stage_begin(struct tamd_stage * st, int space, size_t total_bytes);
 /* returns the device address to use for a user array (NULL stays NULL) */

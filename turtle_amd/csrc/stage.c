@@ -70,10 +70,9 @@ int tamd_stage_out(struct tamd_stage * st, void * user, size_t bytes, void ** de
 int tamd_stage_fetch(struct tamd_stage * st, void * user, size_t bytes, const void * dev)
 {
         if ((user == NULL) || (st->space == TURTLE_AMD_DEVICE)) return 0;
-        char * piece = (st->packed && (st->n_pending < TAMD_STAGE_PENDING)) ? pinned_piece(st, bytes) : NULL;
-        if (piece == NULL) return tamd_dev_d2h(user, dev, bytes);
-        if (tamd_dev_copy_async(piece, dev, bytes, 0)) return 1;
-        st->pending[st->n_pending].user = user, st->pending[st->n_pending].pinned = piece;
+        if (!st->packed || (st->n_pending >= TAMD_STAGE_PENDING)) return tamd_dev_d2h(user, dev, bytes);
+        /* on its way back with the others: see tamd_stage_end */
+        st->pending[st->n_pending].user = user, st->pending[st->n_pending].dev = dev;
         st->pending[st->n_pending].bytes = bytes;
         st->n_pending++;
         return 0;
@@ -82,10 +81,29 @@ int tamd_stage_fetch(struct tamd_stage * st, void * user, size_t bytes, const vo
 int tamd_stage_end(struct tamd_stage * st)
 {
         if (st->space == TURTLE_AMD_DEVICE) return 0;
-        if (tamd_dev_sync()) return 1;
         int i;
-        for (i = 0; i < st->n_pending; i++)
-                memcpy(st->pending[i].user, st->pending[i].pinned, st->pending[i].bytes);
-        st->n_pending = 0;
-        return 0;
+        if (st->n_pending > 0) {
+                /* the outputs are pieces of one arena: ONE copy of the span they cover */
+                const char *lo = st->pending[0].dev, *hi = lo;
+                for (i = 0; i < st->n_pending; i++) {
+                        const char * d = st->pending[i].dev;
+                        if (d < lo) lo = d;
+                        if (d + st->pending[i].bytes > hi) hi = d + st->pending[i].bytes;
+                }
+                char * piece = pinned_piece(st, (size_t)(hi - lo));
+                if (piece == NULL) { /* (cannot be: the buffer holds twice the arena) */
+                        for (i = 0; i < st->n_pending; i++)
+                                if (tamd_dev_d2h(st->pending[i].user, st->pending[i].dev, st->pending[i].bytes))
+                                        return 1;
+                        st->n_pending = 0;
+                        return tamd_dev_sync();
+                }
+                if (tamd_dev_copy_async(piece, lo, (size_t)(hi - lo), 0) || tamd_dev_sync()) return 1;
+                for (i = 0; i < st->n_pending; i++)
+                        memcpy(st->pending[i].user, piece + ((const char *)st->pending[i].dev - lo),
+                            st->pending[i].bytes);
+                st->n_pending = 0;
+                return 0;
+        }
+        return tamd_dev_sync();
 }
