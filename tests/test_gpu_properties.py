@@ -105,24 +105,23 @@ def test_c2_properties(c2):
 
 
 def test_creep_loop_changes_no_bit(tmp_path):
-    """The lean forms of the lined pass take the samples the general
+    """The lean steps of the lined pass take the samples the general
     iteration would take, with the same functions on the same values: a batch with
-    thousands-of-steps rays gives the same bits with the creep loops off
-    (TURTLE_AMD_CREEP_LANES=0), at their default, engaging at any number of live
-    lanes (64), and with the lean sampling of the general iteration off
-    (TURTLE_AMD_LEAN=0: every sample through f_sample_on_line) -- through one map
-    and through a regular stack."""
+    thousands-of-steps rays gives the same bits with the lean loop off
+    (TURTLE_AMD_CREEP_LANES=0 and TURTLE_AMD_DENSE_GO=0), engaging in sparse waves only,
+    at its defaults, and at other thresholds -- through one map and through a regular
+    stack."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     results = {}
-    for lanes, lean in (("0", "0"), ("0", "1"), ("8", "1"), ("64", "1"), ("8", "0")):
-        out = os.path.join(tmp_path, f"lanes{lanes}_{lean}.npz")
-        work = os.path.join(tmp_path, f"work{lanes}_{lean}")
-        env = dict(os.environ, TURTLE_AMD_CREEP_LANES=lanes, TURTLE_AMD_LEAN=lean)
+    for lanes, go in (("0", "0"), ("8", "0"), ("8", "24"), ("64", "0"), ("8", "48"), ("0", "8")):
+        out = os.path.join(tmp_path, f"lanes{lanes}_{go}.npz")
+        work = os.path.join(tmp_path, f"work{lanes}_{go}")
+        env = dict(os.environ, TURTLE_AMD_CREEP_LANES=lanes, TURTLE_AMD_DENSE_GO=go)
         subprocess.run([sys.executable, os.path.join(here, "creep_probe.py"), out, work],
                        check=True, env=env, timeout=300)
-        results[(lanes, lean)] = dict(np.load(out))
+        results[(lanes, go)] = dict(np.load(out))
     base = results[("0", "0")]
     assert base["map_n_steps"].max() > 2000 and base["stack_n_steps"].max() > 2000
     for which, r in results.items():

@@ -1823,6 +1823,7 @@ constexpr int kChunk = 64; /* rays a wave draws from the global queue at once */
 constexpr int kTailChunk = 8; /* ... in the last phase of a fast trace: few, and long */
 constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many live lanes */
 constexpr int kCreepUnroll = 4; /* steps per trip of the one-map creep loop */
+constexpr int kCreepBackoff = 4; /* general iterations a busy wave waits after a useless group */
 
 enum { ST_INIT = 0, ST_STEP = 1, ST_BISECT = 2 };
 
@@ -1879,6 +1880,7 @@ struct PhaseIO {
                               * line (see LINED) */
         int chunk;           /* rays a wave draws from the queue at once */
         int creep_lanes;     /* the creep loop engages at or below this many live lanes */
+        int dense_go;        /* ... and above, while at least this many lanes step on (0: never) */
 };
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
@@ -1904,6 +1906,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
          * bookkeeping costs a wave per SIMD in the one-stack kernel) */
         constexpr bool CAN_FAULT = PAGED && (MODE != TAMD_MODE_ONE_MAP);
         long pool_next = 0, pool_end = 0; /* wave-uniform */
+        int creep_wait = 0;                /* wave-uniform: general iterations before a busy wave tries lean steps again */
         bool exhausted = false;            /* wave-uniform */
         OneCtx ctx;
         d_load_ctx<MODE, FAST>(v, ctx);
@@ -2029,9 +2032,12 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                  * per kCreepUnroll steps: a lane that cannot take one of them takes
                  * none of the following either (nothing is committed from there on),
                  * and the wave leaves after the group. */
+                const int live = __popcll(__ballot(ray >= 0));
+                const bool sparse = (live <= ph.creep_lanes);
+                if (creep_wait > 0) creep_wait--;
                 if (MODEL &&
                     ((MODE == TAMD_MODE_ONE_MAP) || ((MODE == TAMD_MODE_ONE_STACK) && ctx.stack.regular)) &&
-                    (__popcll(__ballot(ray >= 0)) <= ph.creep_lanes)) {
+                    (sparse || ((ph.dense_go > 0) && (creep_wait == 0)))) {
                         /* one map: the grid.  A regular stack: the tile the cached cell is
                          * in -- the shared tile shape at that tile's origin, computed as
                          * f_stack_elevation computes it; a point `interior` to it (same
@@ -2040,38 +2046,45 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         const tamd_grid & g = STACK ? ctx.stack.proto : ctx.grid;
                         constexpr double guard = STACK ? kSeamGuard : 1e-6;
                         const double mx = (double)(g.nx - 1) - guard, my = (double)(g.ny - 1) - guard;
-                        const bool cached = (cell.id != ~0u);
-                        const unsigned slot = STACK ? (cell.id >> 24) : 0u;
-                        const unsigned cell_index = STACK ? (cell.id & 0xffffffu) : cell.id;
-                        const unsigned tile_y = STACK ? slot / (unsigned)ctx.stack.nlon : 0u;
-                        const unsigned tile_x = STACK ? slot - tile_y * (unsigned)ctx.stack.nlon : 0u;
-                        const double x0 = STACK ? ctx.stack.lon0 + (int)tile_x * ctx.stack.dlon : g.x0;
-                        const double y0 = STACK ? ctx.stack.lat0 + (int)tile_y * ctx.stack.dlat : g.y0;
-                        /* The cached cell, decoded once per entry: its node coordinates
-                         * as doubles and its four elevations -- a trip then needs no
-                         * conversion between integers and doubles (a quarter of the
-                         * rate of the other instructions, and on the chain).  Same
-                         * values as f_grid_locate / f_grid_blend produce: for an
-                         * interior point (double)(int)hx == trunc(hx), and the clamp of
-                         * the cell index does nothing. */
-                        const unsigned cell_iy = cached ? cell_index / (unsigned)g.nx : 0u;
-                        const double cy = cached ? (double)cell_iy : -1.;
-                        const double cx = cached ? (double)(cell_index - cell_iy * (unsigned)g.nx) : -1.;
-                        double z00, z10, z01, z11;
-                        if (g.is_signed) {
-                                z00 = (double)(int16_t)(cell.lo & 0xffffu), z10 = (double)((int)cell.lo >> 16);
-                                z01 = (double)(int16_t)(cell.hi & 0xffffu), z11 = (double)((int)cell.hi >> 16);
-                        } else {
-                                z00 = (double)(cell.lo & 0xffffu), z10 = (double)(cell.lo >> 16);
-                                z01 = (double)(cell.hi & 0xffffu), z11 = (double)(cell.hi >> 16);
-                        }
-                        z00 = __builtin_fma(z00, g.dz, g.z0), z10 = __builtin_fma(z10, g.dz, g.z0);
-                        z01 = __builtin_fma(z01, g.dz, g.z0), z11 = __builtin_fma(z11, g.dz, g.z0);
+                        /* The cached cell, decoded once per entry (and after a trip that
+                         * changed it): its origin, its node coordinates as doubles and its
+                         * four elevations -- a step then needs no conversion between
+                         * integers and doubles (a quarter of the rate of the other
+                         * instructions, and on the chain).  Same values as f_grid_locate /
+                         * f_grid_blend produce: for an interior point (double)(int)hx ==
+                         * trunc(hx), and the clamp of the cell index does nothing. */
+                        double x0, y0, cx, cy, z00, z10, z01, z11;
+                        auto decode_nodes = [&]() {
+                                if (g.is_signed) {
+                                        z00 = (double)(int16_t)(cell.lo & 0xffffu), z10 = (double)((int)cell.lo >> 16);
+                                        z01 = (double)(int16_t)(cell.hi & 0xffffu), z11 = (double)((int)cell.hi >> 16);
+                                } else {
+                                        z00 = (double)(cell.lo & 0xffffu), z10 = (double)(cell.lo >> 16);
+                                        z01 = (double)(cell.hi & 0xffffu), z11 = (double)(cell.hi >> 16);
+                                }
+                                z00 = __builtin_fma(z00, g.dz, g.z0), z10 = __builtin_fma(z10, g.dz, g.z0);
+                                z01 = __builtin_fma(z01, g.dz, g.z0), z11 = __builtin_fma(z11, g.dz, g.z0);
+                        };
+                        auto decode_cell = [&]() {
+                                const bool cached = (cell.id != ~0u);
+                                const unsigned slot = STACK ? (cell.id >> 24) : 0u;
+                                const unsigned cell_index = STACK ? (cell.id & 0xffffffu) : cell.id;
+                                const unsigned tile_y = STACK ? slot / (unsigned)ctx.stack.nlon : 0u;
+                                const unsigned tile_x = STACK ? slot - tile_y * (unsigned)ctx.stack.nlon : 0u;
+                                x0 = STACK ? ctx.stack.lon0 + (int)tile_x * ctx.stack.dlon : g.x0;
+                                y0 = STACK ? ctx.stack.lat0 + (int)tile_y * ctx.stack.dlat : g.y0;
+                                const unsigned cell_iy = cached ? cell_index / (unsigned)g.nx : 0u;
+                                cy = cached ? (double)cell_iy : -1.;
+                                cx = cached ? (double)(cell_index - cell_iy * (unsigned)g.nx) : -1.;
+                                decode_nodes();
+                        };
+                        decode_cell();
                         for (int it = 0; it < 4096; it++) {
                                 /* no short-circuits below: every lane computes
                                  * everything (garbage is harmless, nothing is
                                  * committed on failure) and the tests are AND-ed */
-                                bool going = (ray >= 0) & (state == ST_STEP) & lined_ & line.valid;
+                                bool going = (ray >= 0) & (state == ST_STEP) & lined_ & line.valid &
+                                    (!STACK || (cell.id != ~0u)); /* a stack: the tile comes with a cached cell */
 #pragma unroll
                                 for (int u = 0; u < kCreepUnroll; u++) {
                                         const double sl = line.s + ds;
@@ -2084,6 +2097,17 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         const bool interior =
                                             (hx > guard) & (hx < mx) & (hy > guard) & (hy < my);
                                         const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);
+                                        going = going & (count + 1 < max_steps) & (fabs(sl) <= kLineRange) & interior;
+                                        if (going & ((tx != cx) | (ty != cy))) {
+                                                /* another cell of the same grid: what
+                                                 * f_grid_elevation does on a cache miss */
+                                                const int ix = (int)tx, iy = (int)ty;
+                                                const unsigned id = (unsigned)iy * (unsigned)g.nx + (unsigned)ix;
+                                                d_cell_fetch(STACK ? ctx.slots[cell.id >> 24] : g.nodes, g.nbx, ix, iy, cell.lo, cell.hi);
+                                                cell.id = STACK ? ((cell.id & 0xff000000u) | id) : id;
+                                                cx = tx, cy = ty;
+                                                decode_nodes();
+                                        }
                                         /* f_grid_blend */
                                         const double fx = hx - tx, fy = hy - ty;
                                         const double gx = 1. - fx, gy = 1. - fy;
@@ -2092,9 +2116,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                             ctx.offset;
                                         const double clearance = fabs(alt - elevation);
                                         const int mm = (elevation >= alt) ? 0 : 1;
-                                        going = going & (count + 1 < max_steps) & (fabs(sl) <= kLineRange) &
-                                            f_line_serves(line, sl, clearance) & interior &
-                                            (tx == cx) & (ty == cy) & (mm == m);
+                                        going = going & f_line_serves(line, sl, clearance) & (mm == m);
                                         /* d_step_length for one surface: both of its
                                          * cases are |alt - elevation| */
                                         double ds_next = clearance * v.slope;
@@ -2108,7 +2130,22 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         my_samples += going ? 1 : 0;
                                         ds = going ? ds_next : ds;
                                 }
-                                if (__ballot((ray >= 0) & !going) != 0) break;
+                                const bool stopped = (ray >= 0) & !going;
+                                const int n_stopped = __popcll(__ballot(stopped));
+                                if (n_stopped == 0) continue;
+                                if (!sparse) {
+                                        /* a busy wave: the lanes that stopped wait while
+                                         * enough of the others step on (a group of lean
+                                         * steps costs a third of a general iteration, which
+                                         * then serves every lane that waits at once); where
+                                         * the first group already loses most lanes -- rays
+                                         * high above the ground, a new cell every step --
+                                         * the wave does not try again for a while */
+                                        if (live - n_stopped >= ph.dense_go) continue;
+                                        if (it == 0) creep_wait = kCreepBackoff;
+                                        break;
+                                }
+                                break;
                         }
                 }
 
@@ -3008,7 +3045,7 @@ static int env_int(const char * name, int fallback)
 static int park_threshold(void)
 {
         static int value = -1;
-        if (value < 0) value = max(0, env_int("TURTLE_AMD_PARK", 512));
+        if (value < 0) value = max(0, env_int("TURTLE_AMD_PARK", 32));
         return value;
 }
 static int park_threshold_2(void)
@@ -3027,6 +3064,12 @@ static int creep_lanes(long n)
         if (value == -2) value = env_int("TURTLE_AMD_CREEP_LANES", -1);
         if (value >= 0) return value;
         return (n >= 2000000) ? 4 * kCreepLanes : kCreepLanes;
+}
+static int dense_go(void)
+{
+        static int value = -1;
+        if (value < 0) value = env_int("TURTLE_AMD_DENSE_GO", 24);
+        return value;
 }
 static int drain_lanes(void)
 {
@@ -3056,7 +3099,7 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         const bool again = (pg.ids != nullptr);
         if (again) flags |= TRACE_CARRY_MEDIUM;
         const int resume = again ? 2 : 0;
-        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, resume, pg, 0, 0, kChunk, creep_lanes(n) };
+        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, resume, pg, 0, 0, kChunk, creep_lanes(n), dense_go() };
         if (g_math_strict || !view.fast_ok)
                 return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
@@ -3070,17 +3113,17 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         int park2 = park_threshold_2();
         if ((park2 <= park) || (max_steps <= park2)) park2 = 0;
         const PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, resume, pg, drain_lanes(), 0,
-                kChunk, creep_lanes(n) };
+                kChunk, creep_lanes(n), dense_go() };
         if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
                 n_steps, flags, a, stats, queue))
                 return 1;
         const PhaseIO b = { parked, queue + 2, park2 ? parked + n : nullptr, queue + 4, park2, 1, pg,
-                0, park, kChunk, creep_lanes(n) };
+                0, park, kChunk, creep_lanes(n), dense_go() };
         if (launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
                 n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1))
                 return 1;
         if (park2 == 0) return 0;
-        const PhaseIO c = { parked + n, queue + 4, nullptr, nullptr, 0, 1, pg, 0, park, kTailChunk, creep_lanes(n) };
+        const PhaseIO c = { parked + n, queue + 4, nullptr, nullptr, 0, 1, pg, 0, park, kTailChunk, creep_lanes(n), dense_go() };
         return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
             n_steps, flags | TRACE_CARRY_MEDIUM, c, stats, queue + 3);
 }
