@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""What the waves of phase B do (diagnostic build scratch/prof3: counters in k_trace<MODEL>).
-C2, 1 M rays."""
+"""What the waves of the lined pass do (diagnostic build: scripts/exp_phaseb_build.py, then run with
+TURTLE_AMD_LIBRARY=scratch/prof3/libturtle_amd.so).  C2's terrain; rays on the command line."""
 import ctypes as C
 import os
 import sys
@@ -33,4 +33,16 @@ print(f"lean groups: sparse {c[2]:.0f} with {c[4]:.0f} steps ({c[4] / max(1, c[2
       f"busy {c[3]:.0f} with {c[5]:.0f} steps ({c[5] / max(1, c[3]):.2f} per group); busy entries {c[6]:.0f}, backed off {c[7]:.0f}")
 print(f"cycles (sum over waves): lean loops {c[9]:.3g}, general iterations {c[10]:.3g} = {c[10] / max(1, c[0]):.0f} each")
 print(f"first step of a lean group, live lanes {c[12]:.0f}: not stepping {c[13]:.0f}, no line {c[14]:.0f}, rim/range/cap {c[15]:.0f}, "
-      f"another cell {c[16]:.0f}; of those that evaluate: line does not serve {c[17]:.0f}, another medium {c[18]:.0f}, step below 6.25 m {c[19]:.0f}")
+      f"another cell {c[16]:.0f}; of those that evaluate: line does not serve {c[17]:.0f}, another medium {c[18]:.0f}")
+print(f"lanes of the general iterations: not yet on a line {c[20]:.0f}, bisecting {c[21]:.0f}, starting {c[22]:.0f}")
+sp = np.zeros((4096, 4), dtype=np.uint64)
+binding.lib().tamd_dev_span_read(sp.ctypes.data_as(C.c_void_p))
+used = sp[:, 1] > 0
+# (each XCD has its own counter: only differences within a wave mean anything; the waves of a
+# persistent launch start together)
+end = (sp[used, 1] - sp[used, 0]).astype(float)
+dry = np.where(sp[used, 2] > 0, sp[used, 2].astype(float) - sp[used, 0].astype(float), np.nan)
+unit = end.max() / 100.0
+print(f"{used.sum()} waves; the longest lives {end.max():.3g} ticks of s_memtime; in hundredths of that:")
+print("  waves find the queue dry at: " + " ".join(f"{np.nanpercentile(dry, q) / unit:.0f}" for q in (1, 25, 50, 75, 99)) + "  (percentiles 1 25 50 75 99)")
+print("  waves end at:                " + " ".join(f"{np.percentile(end, q) / unit:.0f}" for q in (1, 10, 25, 50, 75, 90, 99)) + "  (percentiles 1 10 25 50 75 90 99)")

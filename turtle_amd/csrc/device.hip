@@ -3042,11 +3042,21 @@ static int env_int(const char * name, int fallback)
 /* Step counts at which a ray moves on to the next phase of a fast trace (0: no
  * further phase), and the rays a wave of phase A may still hold when it hands
  * over after the queue ran dry.  TURTLE_AMD_* override them for experiments. */
-static int park_threshold(void)
+/* The lean steps of the lined pass (one map, a regular stack) cost a tenth of a
+ * closed form in instructions but run in half-empty waves, one dependent chain
+ * each: they win where the launch waits for its longest rays (C2, 1 M rays: 7.2 ms
+ * with the line from step 512 on, 6.0 from step 32; a stack, 3 M rays: 21.6 -> 20.2)
+ * and lose where it is a matter of throughput (the same stack, 10 M rays: 42.9 ->
+ * 49.3 ms: phase A takes 63 G closed forms a second with every lane busy).  Layered
+ * geometries have no lean loop. */
+static int park_threshold(int mode, long n)
 {
-        static int value = -1;
-        if (value < 0) value = max(0, env_int("TURTLE_AMD_PARK", 32));
-        return value;
+        static int value = -2;
+        if (value == -2) value = env_int("TURTLE_AMD_PARK", -1);
+        if (value >= 0) return value;
+        if (mode == TAMD_MODE_GENERIC) return 512;
+        if ((mode == TAMD_MODE_ONE_STACK) && (n >= 5000000)) return 512;
+        return 32;
 }
 static int park_threshold_2(void)
 {
@@ -3103,7 +3113,7 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         if (g_math_strict || !view.fast_ok)
                 return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
-        const int park = park_threshold();
+        const int park = park_threshold(MODE, n);
         if ((parked == nullptr) || (park <= 0) || (max_steps <= park) || (length == nullptr) ||
             (n_steps == nullptr))
                 return launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index,
