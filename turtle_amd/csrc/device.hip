@@ -661,6 +661,16 @@ __device__ __forceinline__ CellAt f_grid_locate(const tamd_grid & g, double x, d
         return c;
 }
 
+/* The bilinear patch over a cell, fast-math form: z00 + fx b + fy (c + fx d) with
+ * b = z10 - z00, c = z01 - z00, d = (z11 - z10) - c -- three fused operations
+ * where the reference's four-term sum [ref map.c:270-276] takes thirteen, within
+ * an ulp or two of it (1e-13 m).  The lean steps of the lined pass keep b, c, d
+ * per cell. */
+__device__ __forceinline__ double f_patch(double z00, double b, double c, double d, double fx, double fy)
+{
+        return __builtin_fma(fy, __builtin_fma(fx, d, c), __builtin_fma(fx, b, z00));
+}
+
 /* the bilinear blend of a cell's four raw nodes (lo = z00 | z10 << 16, hi =
  * z01 | z11 << 16); one function so that every caller rounds identically */
 __device__ __forceinline__ double f_grid_blend(
@@ -677,8 +687,7 @@ __device__ __forceinline__ double f_grid_blend(
         }
         z00 = __builtin_fma(z00, g.dz, g.z0), z10 = __builtin_fma(z10, g.dz, g.z0);
         z01 = __builtin_fma(z01, g.dz, g.z0), z11 = __builtin_fma(z11, g.dz, g.z0);
-        const double gx = 1. - fx, gy = 1. - fy;
-        return z00 * gx * gy + z01 * gx * fy + z10 * fx * gy + z11 * fx * fy;
+        return f_patch(z00, z10 - z00, z01 - z00, (z11 - z10) - (z01 - z00), fx, fy);
 }
 
 __device__ __forceinline__ bool f_grid_elevation(
@@ -999,8 +1008,7 @@ __device__ __forceinline__ int f_stack_elevation(const tamd_view & v,
                         }
                         z00 = __builtin_fma(z00, p.dz, p.z0), z10 = __builtin_fma(z10, p.dz, p.z0);
                         z01 = __builtin_fma(z01, p.dz, p.z0), z11 = __builtin_fma(z11, p.dz, p.z0);
-                        const double gx = 1. - fxc, gy = 1. - fyc;
-                        z = z00 * gx * gy + z01 * gx * fyc + z10 * fxc * gy + z11 * fxc * fyc;
+                        z = f_patch(z00, z10 - z00, z01 - z00, (z11 - z10) - (z01 - z00), fxc, fyc);
                         return 1;
                 }
         }
@@ -2064,6 +2072,8 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                 }
                                 z00 = __builtin_fma(z00, g.dz, g.z0), z10 = __builtin_fma(z10, g.dz, g.z0);
                                 z01 = __builtin_fma(z01, g.dz, g.z0), z11 = __builtin_fma(z11, g.dz, g.z0);
+                                /* f_patch's coefficients, as f_grid_blend forms them */
+                                z11 = (z11 - z10) - (z01 - z00), z10 = z10 - z00, z01 = z01 - z00;
                         };
                         auto decode_cell = [&]() {
                                 const bool cached = (cell.id != ~0u);
@@ -2110,10 +2120,7 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                         }
                                         /* f_grid_blend */
                                         const double fx = hx - tx, fy = hy - ty;
-                                        const double gx = 1. - fx, gy = 1. - fy;
-                                        const double elevation =
-                                            (z00 * gx * gy + z01 * gx * fy + z10 * fx * gy + z11 * fx * fy) +
-                                            ctx.offset;
+                                        const double elevation = f_patch(z00, z10, z01, z11, fx, fy) + ctx.offset;
                                         const double clearance = fabs(alt - elevation);
                                         const int mm = (elevation >= alt) ? 0 : 1;
                                         going = going & f_line_serves(line, sl, clearance) & (mm == m);
@@ -2121,14 +2128,15 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                                          * cases are |alt - elevation| */
                                         double ds_next = clearance * v.slope;
                                         if (ds_next < v.resolution) ds_next = v.resolution;
-                                        bx = going ? bx + dx * ds : bx, by = going ? by + dy * ds : by;
-                                        bz = going ? bz + dz * ds : bz;
-                                        line.tau = going ? line.tau + kLineDrift : line.tau;
-                                        line.s = going ? sl : line.s;
-                                        len = going ? len + ds : len;
-                                        count += going ? 1 : 0;
-                                        my_samples += going ? 1 : 0;
-                                        ds = going ? ds_next : ds;
+                                        if (going) {
+                                                bx = bx + dx * ds, by = by + dy * ds, bz = bz + dz * ds;
+                                                line.tau = line.tau + kLineDrift;
+                                                line.s = sl;
+                                                len = len + ds;
+                                                count++;
+                                                my_samples++;
+                                                ds = ds_next;
+                                        }
                                 }
                                 const bool stopped = (ray >= 0) & !going;
                                 const int n_stopped = __popcll(__ballot(stopped));
