@@ -1830,8 +1830,8 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
 constexpr int kChunk = 64; /* rays a wave draws from the global queue at once */
 constexpr int kTailChunk = 8; /* ... in the last phase of a fast trace: few, and long */
 constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many live lanes */
-constexpr int kCreepUnroll = 4; /* steps per trip of the one-map creep loop */
-constexpr int kCreepBackoff = 4; /* general iterations a busy wave waits after a useless group */
+constexpr int kCreepUnroll = 8; /* steps per trip of the one-map creep loop */
+constexpr int kCreepBackoff = 8; /* general iterations a busy wave waits after a useless group */
 
 enum { ST_INIT = 0, ST_STEP = 1, ST_BISECT = 2 };
 
