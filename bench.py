@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_CLOCK_HZ = 2.4e9       # MI355X peak engine clock (MI355X_MICROARCH.md)
-TRACE_KERNEL = "k_trace (phase A: all rays up to 512 steps; phase B: what is left, long rays on their lines)"
+TRACE_KERNEL = "k_trace (phase A: every ray by the closed form up to its hand-over step, 32 or 512; phase B: the rest on their lines)"
 STEP_KERNELS = "k_step_fast + k_bisect per generation (single steps, directions drawn in the kernel)"
 WALK_KERNEL = "k_walk (a ray's whole walk in one launch: state in registers, directions drawn in the kernel)"
 SEED = 0x5EED2026

@@ -1869,8 +1869,8 @@ enum { TRACE_CARRY_MEDIUM = 1 };
  * 11 327) and a ray's samples are sequential, so a launch lasts as long as its
  * longest ray.  Phase A therefore PARKS any ray that reaches `park_after` steps
  * (its state goes back to the ray arrays, its id to a list) and phase B resumes
- * the parked rays, packed into few waves that run alone on their SIMDs, with
- * each ray's line (MODEL; see RayLine) that makes a creeping ray's sample ~7x cheaper.
+ * the parked rays with each ray's line (MODEL; see RayLine), which makes a sample
+ * a tenth of the closed form's instructions.
  * Which arithmetic a sample uses depends only on the ray's own step count and
  * positions, never on scheduling: results stay deterministic. */
 struct PhaseIO {
@@ -2029,17 +2029,26 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
                         }
                 }
 
-                /* The single-map case gets a leaner body still: only the line and
-                 * the cached cell (no closed form, no fetch inside; a lane that
-                 * needs either leaves for one general iteration).  What a launch
-                 * waits for in the end is ONE ray -- C2's longest takes 11 326 steps,
-                 * most of them here, alone in its wave -- so what counts is the
-                 * latency of a trip, and a good part of that is the wave-wide
-                 * question "does any lane have to leave?" (compare, ballot, branch:
-                 * the vector and scalar units wait for each other).  It is asked once
-                 * per kCreepUnroll steps: a lane that cannot take one of them takes
-                 * none of the following either (nothing is committed from there on),
-                 * and the wave leaves after the group. */
+                /* ---- lean steps (one map, a regular stack) ------------------------
+                 * The lined pass's work horse: a step of a ray on its line over one
+                 * grid is the line (nine fused operations), the cell (its four nodes
+                 * decoded to the patch's coefficients once per cell; fetched here when
+                 * the ray walks into the next one) and the reference's tests -- ~75
+                 * vector instructions where a closed-form sample takes a thousand.
+                 * A lane that needs anything else (a new line, a crossing and its
+                 * bisection, the rim of the grid, the step cap) stops WITHOUT having
+                 * committed that step, and a general iteration below takes it: the
+                 * same functions on the same values, so results do not depend on
+                 * where a step was taken.  "Does any lane have to leave?" is a
+                 * wave-wide question (compare, ballot, branch: the vector and
+                 * scalar units wait for each other): it is asked once per
+                 * kCreepUnroll steps, and a lane that cannot take one of them takes
+                 * none of the following.  In a wave of a handful of rays (the end of
+                 * a launch: C2's longest ray takes 11 326 steps) the group ends when
+                 * any lane stopped; in a busy one the lanes that stopped wait while
+                 * dense_go others step on.  The SIMD's issue slots bound this loop
+                 * (three waves of it keep the vector unit ~90 % busy): what counts is
+                 * the instructions of a step and the share of lanes that take it. */
                 const int live = __popcll(__ballot(ray >= 0));
                 const bool sparse = (live <= ph.creep_lanes);
                 if (creep_wait > 0) creep_wait--;
@@ -2159,9 +2168,9 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
 
                 /* `drain`: once the queue is dry a wave of phase A hands its rays over
                  * as they stand (between two steps) instead of stepping its last few
-                 * to their 512th step with most lanes idle -- measured: the queue of
-                 * C2 is dry after 2.4 ms and the last wave left at 4.5 ms.  Phase B
-                 * packs them again, and has the time: it waits for its longest ray. */
+                 * to the hand-over count with most lanes idle -- measured with the
+                 * hand-over at 512 steps: the queue of C2 is dry after 2.4 ms and the
+                 * last wave left at 4.5 ms.  Phase B packs them again. */
                 const bool drain = !MODEL && (ph.park_after > 0) && exhausted && (ray >= 0) &&
                     (state == ST_STEP) && (__popcll(__ballot(ray >= 0)) <= ph.drain_lanes);
                 bool park = drain;
@@ -3099,16 +3108,16 @@ static int drain_lanes(void)
 /* One round of a trace: all the rays (pg.ids == NULL), or the ones the last
  * round listed because they needed a tile (they carry on from the arrays).
  *
- * Fast arithmetic runs in phases, each with fewer and longer rays than the one
- * before: A steps everything to 512 steps and hands over what is left when its
- * queue runs dry (C2: 260 k of 1 M rays); B takes those to the end.  A ray
- * changes phase at fixed step counts, or (below 512 steps) where its arithmetic
- * does not depend on the phase: see LINED.  A third phase C for the rays beyond
- * a second threshold (TURTLE_AMD_PARK2; a few to a wave, on an otherwise empty
- * chip) is wired in but off: measured on C2, every threshold from 544 to 2 048
- * made the trace slower (8.5-9.5 ms against 7.5 ms) -- what phase B waits for
- * is not its one longest ray but the medium ones (1 000-2 500 steps) stepping in
- * waves that are neither full nor down to a handful of rays. */
+ * Fast arithmetic runs in two phases: A steps every ray by the closed form up to
+ * park_threshold() steps (32, or 512: see there) and hands over what is left; B
+ * takes those to the end on their lines.  A ray changes phase at a fixed step
+ * count, or (below it, when A's queue ran dry) where its arithmetic does not
+ * depend on the phase: see LINED.  A third phase C for the rays beyond a second
+ * threshold (TURTLE_AMD_PARK2; a few to a wave, on an otherwise empty chip) is
+ * wired in but off: measured on C2, every threshold from 256 to 2 048 made the
+ * trace slower (6.9-7.8 ms against 6.0 ms) -- what phase B waits for is not its
+ * one longest ray but the medium ones (1 000-3 000 steps, a thousand of C2's
+ * million) that happen to be drawn from the queue last. */
 template <int MODE>
 static int run_trace(struct tamd_view view, long n, double * pos, const double * dir,
     int max_steps, int * index, double * length, int * n_steps, int flags, int * parked,
