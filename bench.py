@@ -360,6 +360,9 @@ def run_workload(name, args, env, headline):
             bytes_note = "SURVEY 8d trace mode: 8 B x samples + 64 B x rays"
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src, valu = measured_traffic(name, n, TA.get_math())
+        if use_stack and args.stack_size:
+            # the counters were taken with every tile resident: they say nothing of a paged pass
+            traffic, traffic_src, valu = None, None, None
         simds = 4 * TA.compute_units()
         valu_frac = (4.0 * valu / (simds * kernel_ms * 1e-3 * VALU_CLOCK_HZ)) if valu else None
         out = {
