@@ -1892,10 +1892,10 @@ struct PhaseIO {
 };
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
-__global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
+__device__ __forceinline__ void trace_body(const tamd_view & v, long n,
     double * __restrict__ pos, const double * __restrict__ dir, int max_steps,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
-    int flags, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
+    int flags, const PhaseIO & ph, ull * __restrict__ stats, ull * __restrict__ queue)
 {
         if (ph.n_dev != nullptr) n = (long)*ph.n_dev;
         /* MODEL: besides its accumulated position B (bx, by, bz: the reference's
@@ -2339,6 +2339,31 @@ __global__ void __launch_bounds__(256) k_trace(tamd_view v, long n,
         }
 
         block_tally(stats, my_rays, my_steps, my_samples, my_capped);
+}
+
+/* The least waves a SIMD the kernel must fit (registers: 512 / waves).  The lined
+ * pass is bound by what the SIMD issues, with a memory wait every few steps: a
+ * third wave is worth more than the few values that go to scratch for it (a
+ * stack: 188 registers -> 168 and 52 bytes). */
+#ifndef TRACE_STACK_LINED_WAVES
+#define TRACE_STACK_LINED_WAVES 3
+#endif
+template <int MODE, bool FAST, bool MODEL, bool PAGED>
+constexpr int trace_waves()
+{
+        return (FAST && MODEL && !PAGED && (MODE == TAMD_MODE_ONE_STACK)) ? TRACE_STACK_LINED_WAVES : 1;
+}
+
+template <int MODE, bool FAST, bool MODEL, bool PAGED>
+__global__ void __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(trace_waves<MODE, FAST, MODEL, PAGED>())))
+k_trace(tamd_view v, long n,
+    double * __restrict__ pos, const double * __restrict__ dir, int max_steps,
+    int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
+    int flags, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
+{
+        trace_body<MODE, FAST, MODEL, PAGED>(v, n, pos, dir, max_steps, index, length, n_steps, flags,
+            ph, stats, queue);
 }
 
 /* ---- a whole scattering walk per ray ----------------------------------------
@@ -3060,20 +3085,18 @@ static int env_int(const char * name, int fallback)
  * further phase), and the rays a wave of phase A may still hold when it hands
  * over after the queue ran dry.  TURTLE_AMD_* override them for experiments. */
 /* The lean steps of the lined pass (one map, a regular stack) cost a tenth of a
- * closed form in instructions but run in half-empty waves, one dependent chain
- * each: they win where the launch waits for its longest rays (C2, 1 M rays: 7.2 ms
- * with the line from step 512 on, 6.0 from step 32; a stack, 3 M rays: 21.6 -> 20.2)
- * and lose where it is a matter of throughput (the same stack, 10 M rays: 42.9 ->
- * 49.3 ms: phase A takes 63 G closed forms a second with every lane busy).  Layered
- * geometries have no lean loop. */
+ * closed form in instructions: with the line from step 32 on instead of 512, C2
+ * (1 M rays) goes from 7.2 to 6.0 ms, one map at 10 M rays from 36.1 to 35.4, C3
+ * (a stack, 10 M rays) from 42.4 to 39.8 ms -- the last only with the stack's lined
+ * kernel at three waves a SIMD (trace_waves(); at two, 47.5).  Layered geometries
+ * have no lean loop. */
 static int park_threshold(int mode, long n)
 {
         static int value = -2;
+        (void)n;
         if (value == -2) value = env_int("TURTLE_AMD_PARK", -1);
         if (value >= 0) return value;
-        if (mode == TAMD_MODE_GENERIC) return 512;
-        if ((mode == TAMD_MODE_ONE_STACK) && (n >= 5000000)) return 512;
-        return 32;
+        return (mode == TAMD_MODE_GENERIC) ? 512 : 32;
 }
 static int park_threshold_2(void)
 {
