@@ -1172,9 +1172,8 @@ __device__ __forceinline__ void d_sample(const tamd_view & v, const OneCtx & ctx
  * its path parameter).  Returns true in that case.  Which of the two happens
  * depends on the ray's own line and sample only. */
 template <int MODE>
-__device__ __forceinline__ bool f_sample_on_line(const tamd_view & v, const OneCtx & ctx,
-    double x, double y, double z, double dx, double dy, double dz, RayLine & line, double sl,
-    Sample & s, CellCache * cache)
+__device__ __forceinline__ bool f_line_try(const tamd_view & v, const OneCtx & ctx,
+    const RayLine & line, double sl, Sample & s, CellCache * cache)
 {
         bool serves = line.valid && (fabs(sl) <= kLineRange);
         if (serves) {
@@ -1182,10 +1181,25 @@ __device__ __forceinline__ bool f_sample_on_line(const tamd_view & v, const OneC
                 d_classify<MODE, true>(v, ctx, s, cache);
                 serves = f_line_serves(line, sl, fmin(fabs(s.alt - s.e0), fabs(s.alt - s.e1)));
         }
-        if (!serves) {
-                f_to_geodetic(x, y, z, s.lat, s.lon, s.alt, &line, dx, dy, dz);
-                d_classify<MODE, true>(v, ctx, s, cache);
-        }
+        return serves;
+}
+
+template <int MODE>
+__device__ __forceinline__ void f_line_relay(const tamd_view & v, const OneCtx & ctx,
+    double x, double y, double z, double dx, double dy, double dz, RayLine & line, Sample & s,
+    CellCache * cache)
+{
+        f_to_geodetic(x, y, z, s.lat, s.lon, s.alt, &line, dx, dy, dz);
+        d_classify<MODE, true>(v, ctx, s, cache);
+}
+
+template <int MODE>
+__device__ __forceinline__ bool f_sample_on_line(const tamd_view & v, const OneCtx & ctx,
+    double x, double y, double z, double dx, double dy, double dz, RayLine & line, double sl,
+    Sample & s, CellCache * cache)
+{
+        const bool serves = f_line_try<MODE>(v, ctx, line, sl, s, cache);
+        if (!serves) f_line_relay<MODE>(v, ctx, x, y, z, dx, dy, dz, line, s, cache);
         return !serves;
 }
 
@@ -1832,6 +1846,14 @@ constexpr int kTailChunk = 8; /* ... in the last phase of a fast trace: few, and
 constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many live lanes */
 constexpr int kCreepUnroll = 8; /* steps per trip of the one-map creep loop */
 constexpr int kCreepBackoff = 8; /* general iterations a busy wave waits after a useless group */
+#ifndef TRACE_RELAY_BATCH
+#define TRACE_RELAY_BATCH 12
+#endif
+#ifndef TRACE_RELAY_PATIENCE
+#define TRACE_RELAY_PATIENCE 3
+#endif
+constexpr int kRelayBatch = TRACE_RELAY_BATCH;       /* lanes of a busy wave that a closed form waits for ... */
+constexpr int kRelayPatience = TRACE_RELAY_PATIENCE; /* ... at most this many general iterations */
 
 enum { ST_INIT = 0, ST_STEP = 1, ST_BISECT = 2 };
 
@@ -1915,6 +1937,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
         constexpr bool CAN_FAULT = PAGED && (MODE != TAMD_MODE_ONE_MAP);
         long pool_next = 0, pool_end = 0; /* wave-uniform */
         int creep_wait = 0;                /* wave-uniform: general iterations before a busy wave tries lean steps again */
+        int relay_wait = 0;                /* general iterations that lanes of a busy wave have waited for a closed form */
         bool exhausted = false;            /* wave-uniform */
         OneCtx ctx;
         d_load_ctx<MODE, FAST>(v, ctx);
@@ -2176,6 +2199,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                 bool park = drain;
                 TileFault fault = { -1, 0, 0 }; /* the tiles to page in, if any */
                 double fx = 0, fy = 0, fz = 0; /* where the ray goes back to, then */
+                bool defer = false; /* MODEL: the lane waits for a closed form (see below) */
                 if ((ray >= 0) && !drain) {
                         /* ---- one sample at q = B + d * t ---- */
                         double t = 0.;
@@ -2189,15 +2213,37 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                         if (LINED) {
                                 /* B's parameter: -t on a new line (its origin is q),
                                  * and a STEP sample then moves B to q */
-                                if (f_sample_on_line<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line,
-                                        line.s + t, s, (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr))
+                                CellCache * const cache = (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr;
+                                bool relay = !f_line_try<MODE>(v, ctx, line, line.s + t, s, cache);
+                                /* A closed form is a thousand instructions for the
+                                 * whole wave, whoever needs it: in a busy wave the
+                                 * lanes that do (a ray's first sample, a line at its
+                                 * end) wait until there are kRelayBatch of them, or
+                                 * until only they are left, or kRelayPatience general
+                                 * iterations.  Nothing is committed for a lane that
+                                 * waits: it takes this very sample again.  (One map: C2
+                                 * -2.4 %.  Through a stack the same costs 6-9 %, with 20
+                                 * bytes more of scratch in a kernel held to 168 registers.) */
+                                if ((MODE == TAMD_MODE_ONE_MAP) && !sparse) {
+                                        const int n_need = __popcll(__ballot(relay));
+                                        const int n_here = __popcll(__ballot(true));
+                                        const int waited = __builtin_amdgcn_readfirstlane(relay_wait);
+                                        const bool now = (n_need >= kRelayBatch) | (n_need == n_here) |
+                                            (waited >= kRelayPatience);
+                                        relay_wait = ((n_need == 0) | now) ? 0 : waited + 1;
+                                        defer = relay & !now;
+                                        relay = relay & now;
+                                }
+                                if (relay) {
+                                        f_line_relay<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line, s, cache);
                                         line.s = -t;
-                                if (state == ST_STEP) line.s += t;
+                                }
+                                if ((state == ST_STEP) & !defer) line.s += t;
                         } else
                                 d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
                                     (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr);
-                        my_samples++;
-                        if (CAN_FAULT && (s.fault.centre >= 0)) {
+                        my_samples += defer ? 0 : 1;
+                        if (CAN_FAULT && !defer && (s.fault.centre >= 0)) {
                                 /* a tile that is not resident: the ray goes back to
                                  * the arrays as it was BEFORE this sample (before the
                                  * crossing step, if it was bisecting: the bracket is
@@ -2215,8 +2261,8 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                          * costs exec-mask juggling.  Only INIT (once per ray) and
                          * the two endings (located, done) stay branches. */
                         bool done = false, located = false;
-                        if (CAN_FAULT && (fault.centre < 0) && (state == ST_STEP)) home = s.slot;
-                        if (fault.centre >= 0) {
+                        if (CAN_FAULT && !defer && (fault.centre < 0) && (state == ST_STEP)) home = s.slot;
+                        if ((fault.centre >= 0) | defer) {
                                 /* nothing: see below */
                         } else if (state == ST_INIT) {
                                 m = s.m, k = s.k;
@@ -2343,15 +2389,15 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
 
 /* The least waves a SIMD the kernel must fit (registers: 512 / waves).  The lined
  * pass is bound by what the SIMD issues, with a memory wait every few steps: a
- * third wave is worth more than the few values that go to scratch for it (a
- * stack: 188 registers -> 168 and 52 bytes). */
-#ifndef TRACE_STACK_LINED_WAVES
-#define TRACE_STACK_LINED_WAVES 3
+ * third wave is worth more than the few values that go to scratch for it (one
+ * map: 169 registers -> 168, none; a stack: 188 -> 168 and 64 bytes). */
+#ifndef TRACE_LINED_WAVES
+#define TRACE_LINED_WAVES 3
 #endif
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
 constexpr int trace_waves()
 {
-        return (FAST && MODEL && !PAGED && (MODE == TAMD_MODE_ONE_STACK)) ? TRACE_STACK_LINED_WAVES : 1;
+        return (FAST && MODEL && !PAGED && (MODE != TAMD_MODE_GENERIC)) ? TRACE_LINED_WAVES : 1;
 }
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
