@@ -275,7 +275,10 @@ constexpr double kLineTolerance = 2e-10; /* see f_line_serves */
  * not above it is taken again by the closed form AT THE ACCUMULATED POSITION, as
  * phase A would -- which lays a new line there, whose drift starts from nothing
  * (the samples of a bisection all leave from one accumulated position: the line
- * laid at the first of them that is too close to call serves the others). */
+ * laid at the first of them that is too close to call serves the others -- ALL
+ * the others (`bracketed`): it has no drift, and the last halvings of every ray
+ * are within 1e-9 m of the ground, where its truncation (2e-10 m) is the closed
+ * form's own noise.) */
 constexpr double kLineTau0 = 1e-9;  /* m: the truncation allowed near a boundary (2e-10 m) and
                                      * the rounding of latitude and longitude (8e-10 m on the
                                      * ground, a third of that in elevation) */
@@ -295,10 +298,12 @@ struct RayLine {
  * from any boundary, below 2e-10 OF the clearance: all such a sample decides
  * is the length of the next step, to the same relative accuracy.  At latitude
  * 45 this lets a line serve 500 m near the ground and ~2 km in free flight. */
-__device__ __forceinline__ bool f_line_serves(const RayLine & L, double s, double clearance)
+__device__ __forceinline__ bool f_line_serves(const RayLine & L, double s, double clearance,
+    bool bracketed = false)
 {
         const double s2 = s * s;
-        return (L.c4 * s2 * s2 <= kLineTolerance * fmax(clearance, 1.)) & (clearance > L.tau);
+        return (L.c4 * s2 * s2 <= kLineTolerance * fmax(clearance, 1.)) &
+            ((bracketed & (L.tau <= kLineTau0)) | (clearance > L.tau));
 }
 
 __device__ __forceinline__ void f_line_eval(const RayLine & L, double s, double & latitude,
@@ -1173,13 +1178,13 @@ __device__ __forceinline__ void d_sample(const tamd_view & v, const OneCtx & ctx
  * depends on the ray's own line and sample only. */
 template <int MODE>
 __device__ __forceinline__ bool f_line_try(const tamd_view & v, const OneCtx & ctx,
-    const RayLine & line, double sl, Sample & s, CellCache * cache)
+    const RayLine & line, double sl, Sample & s, CellCache * cache, bool bracketed = false)
 {
         bool serves = line.valid && (fabs(sl) <= kLineRange);
         if (serves) {
                 f_line_eval(line, sl, s.lat, s.lon, s.alt);
                 d_classify<MODE, true>(v, ctx, s, cache);
-                serves = f_line_serves(line, sl, fmin(fabs(s.alt - s.e0), fabs(s.alt - s.e1)));
+                serves = f_line_serves(line, sl, fmin(fabs(s.alt - s.e0), fabs(s.alt - s.e1)), bracketed);
         }
         return serves;
 }
@@ -2214,7 +2219,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 /* B's parameter: -t on a new line (its origin is q),
                                  * and a STEP sample then moves B to q */
                                 CellCache * const cache = (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr;
-                                bool relay = !f_line_try<MODE>(v, ctx, line, line.s + t, s, cache);
+                                bool relay = !f_line_try<MODE>(v, ctx, line, line.s + t, s, cache, state == ST_BISECT);
                                 /* A closed form is a thousand instructions for the
                                  * whole wave, whoever needs it: in a busy wave the
                                  * lanes that do (a ray's first sample, a line at its
