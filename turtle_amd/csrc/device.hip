@@ -2163,8 +2163,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                         going = going & f_line_serves(line, sl, clearance) & (mm == m);
                                         /* d_step_length for one surface: both of its
                                          * cases are |alt - elevation| */
-                                        double ds_next = clearance * v.slope;
-                                        if (ds_next < v.resolution) ds_next = v.resolution;
+                                        const double ds_next = fmax(clearance * v.slope, v.resolution);
                                         if (going) {
                                                 bx = bx + dx * ds, by = by + dy * ds, bz = bz + dz * ds;
                                                 line.tau = line.tau + kLineDrift;
