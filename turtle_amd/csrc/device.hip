@@ -666,6 +666,11 @@ __device__ __forceinline__ CellAt f_grid_locate(const tamd_grid & g, double x, d
         return c;
 }
 
+__device__ __forceinline__ unsigned d_upper_word(double x)
+{
+        return (unsigned)((unsigned long long)__double_as_longlong(x) >> 32);
+}
+
 /* The bilinear patch over a cell, fast-math form: z00 + fx b + fy (c + fx d) with
  * b = z10 - z00, c = z01 - z00, d = (z11 - z10) - c -- three fused operations
  * where the reference's four-term sum [ref map.c:270-276] takes thirteen, within
@@ -2143,20 +2148,25 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                         const double hy = (lat - y0) * g.inv_dy;
                                         const bool interior =
                                             (hx > guard) & (hx < mx) & (hy > guard) & (hy < my);
-                                        const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);
                                         going = going & (count + 1 < max_steps) & (fabs(sl) <= kLineRange) & interior;
-                                        if (going & ((tx != cx) | (ty != cy))) {
+                                        /* still in the cached cell <=> 0 <= hx - cx < 1 and the
+                                         * same in y: for a double that is "its upper word,
+                                         * unsigned, is below that of 1.0" (a negative one has
+                                         * the sign bit there, a NaN the exponent's) */
+                                        double fx = hx - cx, fy = hy - cy;
+                                        if (going & ((d_upper_word(fx) >= 0x3ff00000u) | (d_upper_word(fy) >= 0x3ff00000u))) {
                                                 /* another cell of the same grid: what
                                                  * f_grid_elevation does on a cache miss */
+                                                const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);
                                                 const int ix = (int)tx, iy = (int)ty;
                                                 const unsigned id = (unsigned)iy * (unsigned)g.nx + (unsigned)ix;
                                                 d_cell_fetch(STACK ? ctx.slots[cell.id >> 24] : g.nodes, g.nbx, ix, iy, cell.lo, cell.hi);
                                                 cell.id = STACK ? ((cell.id & 0xff000000u) | id) : id;
                                                 cx = tx, cy = ty;
+                                                fx = hx - tx, fy = hy - ty;
                                                 decode_nodes();
                                         }
                                         /* f_grid_blend */
-                                        const double fx = hx - tx, fy = hy - ty;
                                         const double elevation = f_patch(z00, z10, z01, z11, fx, fy) + ctx.offset;
                                         const double clearance = fabs(alt - elevation);
                                         const int mm = (elevation >= alt) ? 0 : 1;
