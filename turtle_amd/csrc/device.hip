@@ -287,7 +287,7 @@ constexpr double kLineDrift = 1e-9; /* m per step: (3 x (2^-31)^2)^0.5 = 8.1e-10
 struct RayLine {
         double s;                /* path parameter of the ray's position B */
         double lat[4], lon[4], alt[4]; /* degrees, degrees, metres; [k]: s^k */
-        double c4;               /* bound on the neglected term: c4 s^4 metres */
+        double k4;               /* kLineTolerance / c4, c4 s^4 metres bounding the neglected term */
         double tau;
         bool valid;
 };
@@ -302,7 +302,7 @@ __device__ __forceinline__ bool f_line_serves(const RayLine & L, double s, doubl
     bool bracketed = false)
 {
         const double s2 = s * s;
-        return (L.c4 * s2 * s2 <= kLineTolerance * fmax(clearance, 1.)) &
+        return (s2 * s2 <= L.k4 * fmax(clearance, 1.)) &
             ((bracketed & (L.tau <= kLineTau0)) | (clearance > L.tau));
 }
 
@@ -377,7 +377,7 @@ __device__ __forceinline__ void f_line_build(RayLine & L, double latitude, doubl
         /* measured (40-digit reference, any direction, h <= 9 km): the
          * fourth-order term is within 1e-21 (1 + tan^3 lat) s^4 metres */
         const double tl = fabs(S) * nu * re;
-        L.c4 = 1.2e-21 * __builtin_fma(tl * tl, tl, 1.5);
+        L.k4 = kLineTolerance / (1.2e-21 * __builtin_fma(tl * tl, tl, 1.5));
         /* not near a pole (1 / cos lat), nor where the longitude wraps; and only
          * where the bound above was measured: s is a LENGTH (a unit direction;
          * the reference steps along any vector, and so does the closed form that
@@ -2131,6 +2131,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 decode_nodes();
                         };
                         decode_cell();
+                        const bool in_rock = (m == 0); /* a lane's medium does not change in here */
                         for (int it = 0; it < 4096; it++) {
                                 /* no short-circuits below: every lane computes
                                  * everything (garbage is harmless, nothing is
@@ -2169,8 +2170,10 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                         /* f_grid_blend */
                                         const double elevation = f_patch(z00, z10, z01, z11, fx, fy) + ctx.offset;
                                         const double clearance = fabs(alt - elevation);
-                                        const int mm = (elevation >= alt) ? 0 : 1;
-                                        going = going & f_line_serves(line, sl, clearance) & (mm == m);
+                                        /* the medium of the sample, (elevation >= alt) ? 0 : 1,
+                                         * is the ray's (0 or 1 over one surface) */
+                                        const bool same = ((elevation >= alt) == in_rock);
+                                        going = going & f_line_serves(line, sl, clearance) & same;
                                         /* d_step_length for one surface: both of its
                                          * cases are |alt - elevation| */
                                         const double ds_next = fmax(clearance * v.slope, v.resolution);
