@@ -127,3 +127,30 @@ def test_creep_loop_changes_no_bit(tmp_path):
     for which, r in results.items():
         for key, ref in base.items():
             assert np.array_equal(r[key], ref), (which, key)
+
+
+def test_hand_over_step_moves_no_result(tmp_path):
+    """A ray goes on its line at a fixed step count (TURTLE_AMD_PARK: 32 by default for one map and
+    for a stack).  That count decides which arithmetic takes which sample -- not
+    what comes out: the same batch (shallow rays, thousands of steps) with the hand-over at step
+    16, 32 (the default), 512 and never (0: one phase, the closed form throughout) ends in the same
+    media, and its path lengths agree to 1e-7 (the bound asked of parity is 1e-6)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    results = {}
+    for park in ("0", "16", "32", "512"):
+        out = os.path.join(tmp_path, f"park{park}.npz")
+        env = dict(os.environ, TURTLE_AMD_PARK=park)
+        subprocess.run([sys.executable, os.path.join(here, "creep_probe.py"), out,
+                        os.path.join(tmp_path, f"work{park}")], check=True, env=env, timeout=300)
+        results[park] = dict(np.load(out))
+    base = results["0"]
+    assert base["map_n_steps"].max() > 2000 and base["stack_n_steps"].max() > 2000
+    for park, r in results.items():
+        for tag in ("map", "stack"):
+            assert np.array_equal(r[f"{tag}_index"], base[f"{tag}_index"]), (park, tag)
+            rel = np.abs(r[f"{tag}_length"] - base[f"{tag}_length"]) / np.maximum(base[f"{tag}_length"], 1.0)
+            assert rel.max() < 1e-7, (park, tag, rel.max())
+            # a grazing ray may take a step more or less; the others take the same number
+            assert (r[f"{tag}_n_steps"] != base[f"{tag}_n_steps"]).mean() < 1e-3, (park, tag)
