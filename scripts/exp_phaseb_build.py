@@ -24,12 +24,12 @@ i = d.index(old)
 d = d[:i] + "        unsigned long long c_[24] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};\n        const unsigned long long span0_ = __builtin_amdgcn_s_memtime();\n        unsigned long long dry_ = 0;\n" + d[i:]
 sub("                                const bool stopped = (ray >= 0) & !going;\n",
     "                                c_[sparse ? 2 : 3] += 1;\n                                const bool stopped = (ray >= 0) & !going;\n")
-sub("                                        my_samples += going ? 1 : 0;\n                                        ds = going ? ds_next : ds;",
-    "                                        my_samples += going ? 1 : 0;\n                                        c_[sparse ? 4 : 5] += going ? 1 : 0;\n                                        ds = going ? ds_next : ds;")
+sub("                                                my_samples++;\n                                                ds = ds_next;",
+    "                                                my_samples++;\n                                                c_[sparse ? 4 : 5] += 1;\n                                                ds = ds_next;")
 sub("                                        if (it == 0) creep_wait = kCreepBackoff;",
     "                                        if (it == 0) creep_wait = kCreepBackoff, c_[7] += 1;")
-sub("                        decode_cell();\n                        for (int it = 0; it < 4096; it++) {",
-    "                        decode_cell();\n                        if (!sparse) c_[6] += 1;\n"
+sub("                        const bool in_rock = (m == 0); /* a lane's medium does not change in here */\n                        for (int it = 0; it < 4096; it++) {",
+    "                        const bool in_rock = (m == 0);\n                        if (!sparse) c_[6] += 1;\n"
     "                        const unsigned long long lt0_ = __builtin_amdgcn_s_memtime();\n"
     "                        for (int it = 0; it < 4096; it++) {")
 sub("                const bool drain = !MODEL && (ph.park_after > 0) && exhausted && (ray >= 0) &&",
@@ -43,24 +43,27 @@ sub("                                break;\n                        }\n        
 sub("                /* ---- park over-long rays (phase A; whole wave takes part) ---- */",
     "                if (MODEL) c_[10] += __builtin_amdgcn_s_memtime() - gt0_;\n"
     "                /* ---- park over-long rays (phase A; whole wave takes part) ---- */")
-sub("                                        line.s + t, s, (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr))\n                                        line.s = -t;",
-    "                                        line.s + t, s, (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr))\n                                        line.s = -t, c_[8] += 1;")
+sub("                                        f_line_relay<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line, s, cache);\n                                        line.s = -t;",
+    "                                        f_line_relay<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line, s, cache);\n                                        line.s = -t, c_[8] += 1;")
+sub("                                        relay_wait = ((n_need == 0) | now) ? 0 : waited + 1;",
+    "                                        relay_wait = ((n_need == 0) | now) ? 0 : waited + 1;\n                                        c_[19] += (relay & now) ? 1 : 0, c_[23] += (relay & !now) ? 1 : 0;")
 sub("                                        going = going & (count + 1 < max_steps) & (fabs(sl) <= kLineRange) & interior;",
     """                                        if ((u == 0) && (ray >= 0)) {
                                                 c_[12] += 1;
                                                 c_[13] += (state != ST_STEP) ? 1 : 0;
                                                 c_[14] += ((state == ST_STEP) && !(lined_ & line.valid)) ? 1 : 0;
                                                 c_[15] += (going && !((count + 1 < max_steps) & (fabs(sl) <= kLineRange) & interior)) ? 1 : 0;
-                                                c_[16] += (going && ((tx != cx) | (ty != cy))) ? 1 : 0;
                                         }
                                         going = going & (count + 1 < max_steps) & (fabs(sl) <= kLineRange) & interior;""")
-sub("                                        going = going & f_line_serves(line, sl, clearance) & (mm == m);",
+sub("                                                const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);\n                                                const int ix = (int)tx, iy = (int)ty;",
+    "                                                if (u == 0) c_[16] += 1;\n                                                const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);\n                                                const int ix = (int)tx, iy = (int)ty;")
+sub("                                        going = going & f_line_serves(line, sl, clearance) & same;",
     """                                        if ((u == 0) && going) {
                                                 c_[17] += !f_line_serves(line, sl, clearance) ? 1 : 0;
-                                                c_[18] += (mm != m) ? 1 : 0;
+                                                c_[18] += !same ? 1 : 0;
                                         }
-                                        going = going & f_line_serves(line, sl, clearance) & (mm == m);""")
-sub("        block_tally(stats, my_rays, my_steps, my_samples, my_capped);\n}\n\n/* ---- a whole scattering walk per ray",
+                                        going = going & f_line_serves(line, sl, clearance) & same;""")
+sub("        block_tally(stats, my_rays, my_steps, my_samples, my_capped);\n}\n\n/* The least waves a SIMD the kernel must fit",
     """        if (MODEL && ((threadIdx.x & 63) == 0)) {
                 const unsigned w_ = (blockIdx.x * 4 + (threadIdx.x >> 6)) & 4095u;
                 g_span[w_][0] = span0_, g_span[w_][1] = __builtin_amdgcn_s_memtime(), g_span[w_][2] = dry_, g_span[w_][3] = c_[0];
@@ -76,7 +79,7 @@ sub("        block_tally(stats, my_rays, my_steps, my_samples, my_capped);\n}\n\
         block_tally(stats, my_rays, my_steps, my_samples, my_capped);
 }
 
-/* ---- a whole scattering walk per ray""")
+/* The least waves a SIMD the kernel must fit""")
 sub('extern "C" int tamd_dev_select(', '''extern "C" int tamd_dev_span_read(unsigned long long * out)
 {
         HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(g_span)));

@@ -34,7 +34,8 @@ print(f"lean groups: sparse {c[2]:.0f} with {c[4]:.0f} steps ({c[4] / max(1, c[2
 print(f"cycles (sum over waves): lean loops {c[9]:.3g}, general iterations {c[10]:.3g} = {c[10] / max(1, c[0]):.0f} each")
 print(f"first step of a lean group, live lanes {c[12]:.0f}: not stepping {c[13]:.0f}, no line {c[14]:.0f}, rim/range/cap {c[15]:.0f}, "
       f"another cell {c[16]:.0f}; of those that evaluate: line does not serve {c[17]:.0f}, another medium {c[18]:.0f}")
-print(f"lanes of the general iterations: not yet on a line {c[20]:.0f}, bisecting {c[21]:.0f}, starting {c[22]:.0f}")
+print(f"lanes of the general iterations: not yet on a line {c[20]:.0f}, bisecting {c[21]:.0f}, starting {c[22]:.0f}; "
+      f"closed forms taken at once {c[19]:.0f}, lane-iterations spent waiting for one {c[23]:.0f}")
 sp = np.zeros((4096, 4), dtype=np.uint64)
 binding.lib().tamd_dev_span_read(sp.ctypes.data_as(C.c_void_p))
 used = sp[:, 1] > 0
