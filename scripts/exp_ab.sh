@@ -12,6 +12,6 @@ for setting in "$@"; do
 import json, sys
 for l in open(sys.argv[1]):
     if l.startswith("{"):
-        d = json.loads(l); print("   kernel ms", round(d["kernel"]["ms"], 3), "steps/s %.4g" % d["value"], "samples", d["kernel"]["samples_per_launch"])
+        d = json.loads(l); print("   kernel ms", round(d["kernel"]["ms"], 3), "steps/s %.4g" % d["value"], "samples", d["kernel"].get("samples_per_launch", d["kernel"].get("samples_per_pass")))
 PY
 done
