@@ -29,7 +29,7 @@ binding.lib().tamd_dev_cnt_read(c.ctypes.data_as(C.c_void_p), 0)
 c = c.astype(float)
 print(f"general iterations (waves) {c[0]:.0f} ({c[11]:.0f} of them with more than creep_lanes live lanes), samples in them {c[1]:.0f} "
       f"= {c[1] / max(1, c[0]):.1f} lanes each; closed forms among them {c[8]:.0f}")
-print(f"lean groups: sparse {c[2]:.0f} with {c[4]:.0f} steps ({c[4] / max(1, c[2]):.2f} per group of 4); "
+print(f"lean groups: sparse {c[2]:.0f} with {c[4]:.0f} steps ({c[4] / max(1, c[2]):.2f} per group); "
       f"busy {c[3]:.0f} with {c[5]:.0f} steps ({c[5] / max(1, c[3]):.2f} per group); busy entries {c[6]:.0f}, backed off {c[7]:.0f}")
 print(f"cycles (sum over waves): lean loops {c[9]:.3g}, general iterations {c[10]:.3g} = {c[10] / max(1, c[0]):.0f} each")
 print(f"first step of a lean group, live lanes {c[12]:.0f}: not stepping {c[13]:.0f}, no line {c[14]:.0f}, rim/range/cap {c[15]:.0f}, "
