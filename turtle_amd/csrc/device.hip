@@ -1213,6 +1213,35 @@ __device__ __forceinline__ bool f_sample_on_line(const tamd_view & v, const OneC
         return !serves;
 }
 
+/* Where a fast trace samples next inside the bracket [ds0, ds1] of a crossing
+ * [ref stepper.c:840-860 halves it, 27 times from a metre to 1e-8 m].  c0, c1:
+ * the clearances (distance to the nearest boundary, >= 0) of the samples at its
+ * two ends -- over a bracket of a metre or less both measure the same boundary:
+ * the crossing is where they interpolate to zero (false position, with the
+ * Illinois rule: the clearance of an end that has stayed put while the other moved
+ * twice is halved, or a bent surface would keep every sample on one side).  The
+ * sample is taken 0.4e-8 m to the side of that estimate whose end is the farther
+ * one, so that once the estimate is good the two ends close in from both sides:
+ * two such samples and the bracket is 0.8e-8 m wide, where the reference's test
+ * ends it too, around the same crossing (both brackets hold it, both are below
+ * 1e-8 m: the end points agree to that).  A bracket stays a bracket whatever the
+ * estimate is worth (a cell's edge, another layer nearby, a first clearance that
+ * was only guessed); after kBracketPatience samples the midpoint takes over. */
+constexpr int kBracketPatience = 24;
+__device__ __forceinline__ double f_bracket_point(double ds0, double ds1, double c0, double c1,
+    int taken)
+{
+        const double w = ds1 - ds0;
+        const double sum = c0 + c1;
+        double t = 0.5 * (ds0 + ds1);
+        if ((taken < kBracketPatience) && (sum > 0.) && (sum < 1e30) && (w > 2.5e-8)) {
+                const double r = ds0 + w * (c0 / sum);
+                const double aim = ((r - ds0) >= (ds1 - r)) ? r - 0.4e-8 : r + 0.4e-8;
+                t = fmin(fmax(aim, ds0 + 0.25e-8), ds1 - 0.25e-8);
+        }
+        return t;
+}
+
 /* [ref stepper.c:799-813] tentative step length from the last sample */
 __device__ __forceinline__ double d_step_length(
     const tamd_view & v, double alt, double e0, double e1, int m)
@@ -1958,6 +1987,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
         int state = ST_INIT, count = 0, count0 = 0;
         double bx = 0, by = 0, bz = 0, dx = 0, dy = 0, dz = 0, len = 0;
         double ds = 0, ds0 = 0, ds1 = 0;
+        double c0 = 0, c1 = 0; /* FAST: the clearances at the two ends of the bracket (f_bracket_point) */
         int m = -1, k = -1, bm = -1, bk = -1, halvings = 0;
         int home = -1; /* CAN_FAULT: the tile of the ray's last sample (see Sample.slot) */
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_capped = 0;
@@ -2221,7 +2251,8 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                         /* ---- one sample at q = B + d * t ---- */
                         double t = 0.;
                         if (state == ST_STEP) t = ds;
-                        if (state == ST_BISECT) t = 0.5 * (ds0 + ds1);
+                        if (state == ST_BISECT)
+                                t = FAST ? f_bracket_point(ds0, ds1, c0, c1, halvings & 0xffff) : 0.5 * (ds0 + ds1);
                         double qx = bx, qy = by, qz = bz;
                         if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
                                 qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
@@ -2317,12 +2348,23 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 /* the bracket [ref stepper.c:836, :849-858] */
                                 ds0 = cross ? -ds : ((!stepping & same) ? t : ds0);
                                 ds1 = cross ? 0. : ((!stepping & other) ? t : ds1);
+                                int moved_twice = 0; /* bit 16 / 17 of halvings: the last sample moved ds0 / ds1 */
+                                if (FAST) {
+                                        /* the clearance where the crossing step began is
+                                         * what sized it (more, if the resolution did: a guess) */
+                                        const double cl = fmin(fabs(s.alt - s.e0), fabs(s.alt - s.e1));
+                                        const bool again0 = !stepping & same & ((halvings & 0x10000) != 0);
+                                        const bool again1 = !stepping & other & ((halvings & 0x20000) != 0);
+                                        c0 = cross ? ds / v.slope : ((!stepping & same) ? cl : (again1 ? 0.5 * c0 : c0));
+                                        c1 = (cross | (!stepping & other)) ? cl : (again0 ? 0.5 * c1 : c1);
+                                        moved_twice = stepping ? 0 : (same ? 0x10000 : 0x20000);
+                                }
                                 ds = accept ? ds_next : ds; /* a crossing keeps the tentative length */
                                 count += accept ? 1 : 0;
                                 /* a bracket of finite doubles is below 1e-8 after at
                                  * most ~1100 halvings; the cap only guards against
                                  * non-finite input (a kernel must always end) */
-                                halvings = stepping ? 0 : halvings + 1;
+                                halvings = stepping ? 0 : (((halvings & 0xffff) + 1) | moved_twice);
                                 state = cross ? ST_BISECT : state;
                                 const bool capped = accept & (count >= max_steps);
                                 done = capped;
@@ -2340,7 +2382,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                         state = ST_INIT;
                                 }
                                 located = (state == ST_BISECT) &
-                                    (!(ds1 - ds0 > 1E-08) | (halvings > 1200));
+                                    (!(ds1 - ds0 > 1E-08) | ((halvings & 0xffff) > 1200));
                         }
                         if (located) { /* [ref stepper.c:861-863] */
                                 bx = bx + dx * ds1, by = by + dy * ds1, bz = bz + dz * ds1;
