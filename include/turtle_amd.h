@@ -284,7 +284,12 @@ TURTLE_API int turtle_amd_compute_units(void);
  *   FAST    (default) the same algorithm with shared reciprocals, rsqrt-based
  *           roots, one polynomial arctangent and FMAs: ~3x fewer instructions
  *           per sample; coordinates differ from STRICT by a few ulp (<= 3e-9 m
- *           in altitude), path lengths by <= 1e-9 relative.
+ *           in altitude), path lengths by <= 5e-8 relative.  In
+ *           turtle_stepper_trace_n a long ray samples a cubic Taylor line of
+ *           the transform along its path (truncation <= 2e-10 m near a
+ *           boundary) and a crossing is located inside the reference's bracket
+ *           by false position rather than by halving: the same end point to
+ *           1e-8 m, the same medium and step count.
  * Both are checked against the reference's golden vectors at the 1e-6 bar.
  * Every other kernel (elevation, position, step, the other ecef transforms)
  * is always STRICT. */
