@@ -5,18 +5,20 @@ workload that changes as it runs: the scattering walk's later generations)."""
 import csv
 import glob
 import os
+import re
 import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-want = sys.argv[2] if len(sys.argv) > 2 else "k_trace"
+want = sys.argv[2] if len(sys.argv) > 2 else "k_trace|k_cross"  # a regex
 acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(path)):
         name = row["Kernel_Name"]
-        if want not in name:
+        m = re.search(want, name)
+        if not m:
             continue
-        short = name[name.find(want):].split("(")[0] + " grid=" + row["Grid_Size"]
+        short = name[m.start():].split("(")[0] + " grid=" + row["Grid_Size"]
         acc[short][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
 for kern, ctr in acc.items():
     print(f"== {kern}")

@@ -26,8 +26,8 @@ write = sum(k.get("WRITE_SIZE", 0.0) for k in kernels.values())
 json.dump({
     "workload": workload, "rays_per_gpu": rays, "math": math,
     "source_hash": h.hexdigest()[:16],
-    "how": "rocprofv3 --pmc, separate passes (scripts/profile_round.sh); per trace_n call = phase A + "
-           "phase B kernels; FETCH_SIZE/WRITE_SIZE are KB of L2<->fabric requests (Infinity-Cache hits "
+    "how": "rocprofv3 --pmc, separate passes (scripts/profile_round.sh); per trace_n call = phase A + phase B + "
+           "k_cross kernels; FETCH_SIZE/WRITE_SIZE are KB of L2<->fabric requests (Infinity-Cache hits "
            "included); NOT multiplied by the guide's x2 wide-stream correction, which is uncalibrated "
            "for 4-byte gathers",
     "fetch_kb_per_launch": fetch, "write_kb_per_launch": write,

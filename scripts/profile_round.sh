@@ -9,7 +9,7 @@ wl=${2:-c2}
 rays=${3:-0}
 passes=${4:-A B C D}
 WL="--workload $wl --rays $rays --also none"
-kernel=k_trace; [ "$wl" = c5 ] && kernel=k_walk
+kernel="k_trace|k_cross"; [ "$wl" = c5 ] && kernel=k_walk
 out=gpurun_out/$tag
 mkdir -p $out
 timeout -k 10 600 python3 bench.py $WL > $out/bench.json 2> $out/bench.err
@@ -18,7 +18,7 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s
     python3 bench.py $WL --no-cpu > $out/stats.log 2>&1
 echo "stats exit $?"
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv 2>/dev/null
-python3 scripts/trace_timeline.py $out/stats $kernel > $out/timeline.txt 2>&1; tail -4 $out/timeline.txt
+python3 scripts/trace_timeline.py $out/stats "$kernel" > $out/timeline.txt 2>&1; tail -4 $out/timeline.txt
 head -4 $out/kernel_stats.csv | cut -c1-220
 run() { name=$1; shift
   case " $passes " in *" $name "*) ;; *) return;; esac
@@ -30,7 +30,7 @@ run C FETCH_SIZE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F
 run D WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 run E TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum
 if [ "$passes" != none ]; then
-  python3 scripts/pmc_summary.py $out $kernel > $out/pmc_summary.txt
+  python3 scripts/pmc_summary.py $out "$kernel" > $out/pmc_summary.txt
   nrays=$(python3 -c "import json; print(json.loads(open('$out/bench.json').read().strip().splitlines()[-1])['config']['rays_per_gpu'])")
   python3 scripts/pmc_to_json.py $out/pmc_summary.txt $wl $nrays fast > $out/pmc.json
   cat $out/pmc_summary.txt

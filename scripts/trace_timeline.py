@@ -2,7 +2,7 @@
 """Per-dispatch durations of the trace kernels from a rocprofv3 --kernel-trace CSV:
 the passes of the LAST trace of the run, in launch order, and their sum.
 
-usage: trace_timeline.py <dir with *_kernel_trace.csv> [kernel-name substring]"""
+usage: trace_timeline.py <dir with *_kernel_trace.csv> [kernel-name regex]"""
 import csv
 import glob
 import os
@@ -10,7 +10,7 @@ import re
 import sys
 
 root = sys.argv[1]
-want = sys.argv[2] if len(sys.argv) > 2 else "k_trace"
+want = sys.argv[2] if len(sys.argv) > 2 else "k_trace|k_cross"
 files = glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)
 if not files:
     sys.exit("no kernel trace under " + root)
@@ -19,7 +19,7 @@ for f in files:
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-sel = [r for r in rows if want in r[2]]
+sel = [r for r in rows if re.search(want, r[2])]
 if not sel:
     sys.exit("no dispatch of " + want)
 # group dispatches separated by less than 200 us from each other: one trace call

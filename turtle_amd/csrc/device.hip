@@ -1620,7 +1620,16 @@ struct CrossList {
         int * ray;      /* NULL: the step kernel bisects in place */
         double * ds;
         ull * count;
+        int * other;    /* traces: the medium and data index of the sample that crossed,
+                         * packed (cross_pack); batches of single steps: NULL */
 };
+
+/* (medium, data index) of a sample, each -1 .. 65 534, in one int */
+__device__ __forceinline__ int cross_pack(int m, int k) { return (m + 1) | ((k + 1) << 16); }
+__device__ __forceinline__ void cross_unpack(int packed, int & m, int & k)
+{
+        m = (packed & 0xffff) - 1, k = (int)((unsigned)packed >> 16) - 1;
+}
 
 /* One turtle_stepper_step per thread [ref stepper.c:780-875].  With a direction
  * a step is one sample at the tentative position -- and, for the few rays whose
@@ -1950,9 +1959,18 @@ struct PhaseIO {
         int chunk;           /* rays a wave draws from the queue at once */
         int creep_lanes;     /* the creep loop engages at or below this many live lanes */
         int dense_go;        /* ... and above, while at least this many lanes step on (0: never) */
+        CrossList cross;     /* CROSS: where to list the rays whose step crossed a boundary */
 };
 
-template <int MODE, bool FAST, bool MODEL, bool PAGED>
+/* CROSS: a ray whose step crossed a boundary is not bisected here (ST_BISECT
+ * does not exist then: ~11-27 further samples of ONE lane, each a whole general
+ * iteration of its wave -- measured on C2's lined pass: 65 % of the wave-cycles
+ * for 15 % of the samples) but handed over as it stands at the tentative point --
+ * position, the medium it left, path length and step count in the ray arrays;
+ * its id, the tentative length and the medium the sample found in ph.cross -- and
+ * k_cross locates every crossing of the batch afterwards, in full waves.  The
+ * lane takes a new ray at once. */
+template <int MODE, bool FAST, bool MODEL, bool PAGED, bool CROSS>
 __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
     double * __restrict__ pos, const double * __restrict__ dir, int max_steps,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
@@ -2247,11 +2265,12 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                 TileFault fault = { -1, 0, 0 }; /* the tiles to page in, if any */
                 double fx = 0, fy = 0, fz = 0; /* where the ray goes back to, then */
                 bool defer = false; /* MODEL: the lane waits for a closed form (see below) */
+                bool crossed = false; /* CROSS: the step crossed a boundary: the ray goes on the list */
                 if ((ray >= 0) && !drain) {
                         /* ---- one sample at q = B + d * t ---- */
                         double t = 0.;
                         if (state == ST_STEP) t = ds;
-                        if (state == ST_BISECT)
+                        if (!CROSS && (state == ST_BISECT))
                                 t = FAST ? f_bracket_point(ds0, ds1, c0, c1, halvings & 0xffff) : 0.5 * (ds0 + ds1);
                         double qx = bx, qy = by, qz = bz;
                         if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
@@ -2262,7 +2281,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 /* B's parameter: -t on a new line (its origin is q),
                                  * and a STEP sample then moves B to q */
                                 CellCache * const cache = (MODE != TAMD_MODE_GENERIC) ? &cell : nullptr;
-                                bool relay = !f_line_try<MODE>(v, ctx, line, line.s + t, s, cache, state == ST_BISECT);
+                                bool relay = !f_line_try<MODE>(v, ctx, line, line.s + t, s, cache, !CROSS && (state == ST_BISECT));
                                 /* A closed form is a thousand instructions for the
                                  * whole wave, whoever needs it: in a busy wave the
                                  * lanes that do (a ray's first sample, a line at its
@@ -2298,7 +2317,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                  * not kept) and on the list for the next round */
                                 fault = s.fault;
                                 if (state == ST_INIT) home = -1; /* a new ray: nothing to keep */
-                                const double back = (state == ST_BISECT) ? ds : 0.;
+                                const double back = (!CROSS && (state == ST_BISECT)) ? ds : 0.;
                                 fx = bx - dx * back, fy = by - dy * back, fz = bz - dz * back;
                         }
 
@@ -2332,6 +2351,29 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 }
                                 state = ST_STEP;
                                 done = (m < 0) || (count >= max_steps);
+                        } else if (CROSS) {
+                                /* every sample is a STEP sample: it stands, or the ray
+                                 * goes on the list of the crossings (below) */
+                                const bool same = (s.m == m);
+                                const double ds_next = d_step_length(v, s.alt, s.e0, s.e1, s.m);
+                                bx = qx, by = qy, bz = qz; /* [ref stepper.c:824] */
+                                crossed = !same;           /* [ref stepper.c:832-838] */
+                                bm = s.m, bk = s.k;
+                                if (MODEL) line.tau = same ? line.tau + kLineDrift : line.tau;
+                                len = same ? len + ds : len;
+                                k = same ? s.k : k;
+                                ds = same ? ds_next : ds; /* a crossing keeps the tentative length */
+                                count += same ? 1 : 0;
+                                const bool capped = same & (count >= max_steps);
+                                done = capped;
+                                my_capped += capped ? 1 : 0;
+                                park = same & !capped & (ph.park_after > 0) & (count >= ph.park_after);
+                                if (MODEL && same && !capped && !park && !lined_ &&
+                                    (count >= ph.line_after)) {
+                                        lined_ = true; /* (see the other branch) */
+                                        line.valid = false, line.s = 0.;
+                                        state = ST_INIT;
+                                }
                         } else {
                                 const bool stepping = (state == ST_STEP);
                                 const bool same = (s.m == m);
@@ -2421,6 +2463,31 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 ray = -1;
                         }
                 }
+                /* ---- list the rays that crossed a boundary (whole wave takes part) ---- */
+                if (CROSS) {
+                        const ull cmask = __ballot(crossed);
+                        if (cmask != 0) {
+                                const int leader = __builtin_ctzll(cmask);
+                                ull base = 0;
+                                if ((int)(threadIdx.x & 63) == leader)
+                                        base = atomicAdd(ph.cross.count, (ull)__popcll(cmask));
+                                base = __shfl(base, leader, 64);
+                                if (crossed) {
+                                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cmask >> 32),
+                                            __builtin_amdgcn_mbcnt_lo((unsigned)cmask, 0));
+                                        ph.cross.ray[base + rank] = (int)ray;
+                                        ph.cross.ds[base + rank] = ds;
+                                        ph.cross.other[base + rank] = cross_pack(bm, bk);
+                                        /* B is the tentative point; m, k the medium it left */
+                                        pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
+                                        index[2 * ray] = m, index[2 * ray + 1] = k;
+                                        length[ray] = len;
+                                        n_steps[ray] = count;
+                                        my_steps += (ull)(count - count0);
+                                        ray = -1;
+                                }
+                        }
+                }
                 /* ---- list the rays that wait for a tile (whole wave takes part) ---- */
                 if (CAN_FAULT && (ph.pg.faulted != nullptr)) {
                         const bool waits = fault.centre >= 0;
@@ -2438,7 +2505,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 my_steps += (ull)(count - count0);
                         }
                         /* a bisecting ray also wants the tile of its crossing sample */
-                        page_fault(ph.pg, fault, ray, (state == ST_BISECT) ? home : -1);
+                        page_fault(ph.pg, fault, ray, (!CROSS && (state == ST_BISECT)) ? home : -1);
                         if (waits) ray = -1;
                 }
         }
@@ -2459,7 +2526,7 @@ constexpr int trace_waves()
         return (FAST && MODEL && !PAGED && (MODE != TAMD_MODE_GENERIC)) ? TRACE_LINED_WAVES : 1;
 }
 
-template <int MODE, bool FAST, bool MODEL, bool PAGED>
+template <int MODE, bool FAST, bool MODEL, bool PAGED, bool CROSS>
 __global__ void __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(trace_waves<MODE, FAST, MODEL, PAGED>())))
 k_trace(tamd_view v, long n,
@@ -2467,8 +2534,112 @@ k_trace(tamd_view v, long n,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
     int flags, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
 {
-        trace_body<MODE, FAST, MODEL, PAGED>(v, n, pos, dir, max_steps, index, length, n_steps, flags,
+        trace_body<MODE, FAST, MODEL, PAGED, CROSS>(v, n, pos, dir, max_steps, index, length, n_steps, flags,
             ph, stats, queue);
+}
+
+/* The crossings of a trace, every lane busy: for each listed ray the bracket
+ * [-ds, 0] behind its tentative point q is narrowed below 1e-8 m [ref
+ * stepper.c:832-864] -- by halving, on closed-form samples, in the reference's
+ * arithmetic; in the fast one by false position (f_bracket_point) on the line
+ * that the closed form lays AT q: it has no drift (the samples all leave from q)
+ * and serves every sample within its reach, ~500 m; beyond, a sample is a closed
+ * form that lays the next line.  The first sample is q again: the trace kernel
+ * decided there that the medium changed (`other`), by this very closed form or
+ * by the ray's line within its error bound of it; where the two disagree (a
+ * boundary within 1e-9 m of q) the trace kernel's word stands, so that a listed
+ * ray always ends here.  A ray that needs a tile which is not resident goes back
+ * before its step and on the pager's list, as in k_trace. */
+template <int MODE, bool FAST, bool PAGED>
+__global__ void __launch_bounds__(256) k_cross(tamd_view v, double * __restrict__ pos,
+    const double * __restrict__ dir, int * __restrict__ index, double * __restrict__ length,
+    int * __restrict__ n_steps, CrossList cross, Paging pg, ull * __restrict__ stats)
+{
+        constexpr bool CAN_FAULT = PAGED && (MODE != TAMD_MODE_ONE_MAP);
+        OneCtx ctx;
+        d_load_ctx<MODE, FAST>(v, ctx);
+        const long n = (long)*cross.count;
+        ull my_rays = 0, my_samples = 0;
+        for (long i0 = blockIdx.x * (long)blockDim.x; i0 < n; i0 += (long)gridDim.x * blockDim.x) {
+                const long i = i0 + threadIdx.x; /* whole waves go round (page_fault) */
+                TileFault fault = { -1, 0, 0 };
+                int home = -1;
+                long r = -1;
+                if (i < n) {
+                        r = cross.ray[i];
+                        const double ds = cross.ds[i];
+                        int bm, bk;
+                        cross_unpack(cross.other[i], bm, bk);
+                        const double px = pos[3 * r], py = pos[3 * r + 1], pz = pos[3 * r + 2];
+                        const double dx = dir[3 * r], dy = dir[3 * r + 1], dz = dir[3 * r + 2];
+                        const int medium0 = index[2 * r];
+                        CellCache cell = { ~0u, 0u, 0u, -1, nullptr };
+                        CellCache * cache = (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr;
+                        Sample s;
+                        RayLine line;
+                        double at = 0.; /* q's parameter on the line */
+                        if (FAST) {
+                                f_to_geodetic(px, py, pz, s.lat, s.lon, s.alt, &line, dx, dy, dz);
+                                d_classify<MODE, true>(v, ctx, s, cache);
+                        } else
+                                d_sample<MODE, false>(v, ctx, px, py, pz, s, cache);
+                        my_samples++;
+                        if (CAN_FAULT) fault = s.fault, home = s.slot;
+                        const bool agreed = (fault.centre < 0) && (s.m != medium0);
+                        if (agreed) bm = s.m, bk = s.k;
+                        double ds0 = -ds, ds1 = 0.;
+                        /* the clearances at the two ends (f_bracket_point): the one where
+                         * the step began is what sized it (more, if the resolution did) */
+                        double c0 = ds / v.slope;
+                        double c1 = agreed ? fmin(fabs(s.alt - s.e0), fabs(s.alt - s.e1)) : 0.;
+                        int taken = 0, last = 0; /* last: the end the previous sample moved (1: ds0, 2: ds1) */
+                        while ((fault.centre < 0) && (ds1 - ds0 > 1E-08) && (taken <= 1200)) {
+                                const double t = FAST ? f_bracket_point(ds0, ds1, c0, c1, taken) :
+                                                        0.5 * (ds0 + ds1);
+                                const double qx = px + dx * t, qy = py + dy * t, qz = pz + dz * t;
+                                Sample s2;
+                                if (FAST) {
+                                        if (!f_line_try<MODE>(v, ctx, line, at + t, s2, cache, true)) {
+                                                f_line_relay<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line, s2, cache);
+                                                at = -t; /* a new line, laid at this sample */
+                                        }
+                                } else
+                                        d_sample<MODE, false>(v, ctx, qx, qy, qz, s2, cache);
+                                my_samples++, taken++;
+                                if (CAN_FAULT && (s2.fault.centre >= 0)) {
+                                        fault = s2.fault;
+                                } else if (s2.m == medium0) {
+                                        ds0 = t;
+                                        if (FAST) {
+                                                c0 = fmin(fabs(s2.alt - s2.e0), fabs(s2.alt - s2.e1));
+                                                if (last == 1) c1 = 0.5 * c1; /* the Illinois rule */
+                                                last = 1;
+                                        }
+                                } else {
+                                        ds1 = t;
+                                        bm = s2.m, bk = s2.k;
+                                        if (FAST) {
+                                                c1 = fmin(fabs(s2.alt - s2.e0), fabs(s2.alt - s2.e1));
+                                                if (last == 2) c0 = 0.5 * c0;
+                                                last = 2;
+                                        }
+                                }
+                        }
+                        if (fault.centre >= 0) {
+                                /* back before the step, which the next round takes again */
+                                pos[3 * r] = px - dx * ds, pos[3 * r + 1] = py - dy * ds, pos[3 * r + 2] = pz - dz * ds;
+                                pg.tentative[r] = ds;
+                        } else { /* [ref stepper.c:861-863] */
+                                pos[3 * r] = px + dx * ds1, pos[3 * r + 1] = py + dy * ds1, pos[3 * r + 2] = pz + dz * ds1;
+                                index[2 * r] = bm, index[2 * r + 1] = bk;
+                                length[r] = length[r] + (ds + ds1);
+                                n_steps[r] = n_steps[r] + 1;
+                                my_rays++;
+                        }
+                }
+                if (CAN_FAULT && (pg.faulted != nullptr)) page_fault(pg, fault, r, home);
+        }
+        block_tally(stats, my_rays, my_rays, my_samples, 0);
 }
 
 /* ---- a whole scattering walk per ray ----------------------------------------
@@ -3108,7 +3279,7 @@ extern "C" int tamd_k_step(struct tamd_view view, long n, double * pos,
 {
         if (tamd_dev_init()) return 1;
         if (n <= 0) return 0;
-        const CrossList none = { nullptr, nullptr, nullptr };
+        const CrossList none = { nullptr, nullptr, nullptr, nullptr };
         const StepWalk no_walk = { 0, 0, 0, 0, nullptr, nullptr };
         return run_step(view, n, pos, dir, lat, lon, alt, elev, step, index, flags, none, pg,
             nullptr, no_walk);
@@ -3136,12 +3307,12 @@ static int trace_blocks_per_cu(const void * kernel)
 extern "C" void tamd_dev_math_set(int strict) { g_ctx.math_strict = strict ? 1 : 0; }
 extern "C" int tamd_dev_math_get(void) { return g_ctx.math_strict; }
 
-template <int MODE, bool FAST, bool MODEL, bool PAGED>
+template <int MODE, bool FAST, bool MODEL, bool PAGED, bool CROSS>
 static int launch_trace_(struct tamd_view view, long n, bool n_on_device, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
     int flags, PhaseIO ph, ull * stats, ull * queue)
 {
-        const void * kernel = (const void *)k_trace<MODE, FAST, MODEL, PAGED>;
+        const void * kernel = (const void *)k_trace<MODE, FAST, MODEL, PAGED, CROSS>;
         long blocks = (long)g_cus * trace_blocks_per_cu(kernel);
         const long useful = (n + 255) / 256;
         if (!n_on_device && (blocks > useful)) blocks = useful;
@@ -3160,24 +3331,59 @@ static int launch_trace_(struct tamd_view view, long n, bool n_on_device, double
                 if (wide < (long)g_cus) wide = (long)g_cus;
                 if (blocks > wide) blocks = wide;
         }
-        hipLaunchKernelGGL((k_trace<MODE, FAST, MODEL, PAGED>), dim3((unsigned)blocks), dim3(256),
+        hipLaunchKernelGGL((k_trace<MODE, FAST, MODEL, PAGED, CROSS>), dim3((unsigned)blocks), dim3(256),
             0, g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, ph, stats,
             queue);
         LAUNCH_CHECK("k_trace");
         return 0;
 }
 
+/* the instance for this call: PAGED where tiles may have to come in, CROSS where
+ * there is a list for the crossings (always, for a lined pass) */
 template <int MODE, bool FAST, bool MODEL>
 static int launch_trace(struct tamd_view view, long n, bool n_on_device, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
     int flags, PhaseIO ph, ull * stats, ull * queue)
 {
-        if ((MODE != TAMD_MODE_ONE_MAP) && (ph.pg.faulted != nullptr))
-                return launch_trace_<MODE, FAST, MODEL, (MODE != TAMD_MODE_ONE_MAP)>(view, n,
-                    n_on_device, pos, dir, max_steps, index, length, n_steps, flags, ph, stats,
-                    queue);
-        return launch_trace_<MODE, FAST, MODEL, false>(view, n, n_on_device, pos, dir, max_steps,
-            index, length, n_steps, flags, ph, stats, queue);
+#define TRACE_ARGS view, n, n_on_device, pos, dir, max_steps, index, length, n_steps, flags, ph, stats, queue
+        constexpr bool CAN_PAGE = (MODE != TAMD_MODE_ONE_MAP);
+        const bool paged = CAN_PAGE && (ph.pg.faulted != nullptr);
+        const bool cross = (ph.cross.ray != nullptr);
+        if (MODEL && !cross) {
+                snprintf(g_error, sizeof(g_error), "k_trace: a lined pass needs the crossing list");
+                return 1;
+        }
+        if (paged) {
+                if (cross) return launch_trace_<MODE, FAST, MODEL, CAN_PAGE, true>(TRACE_ARGS);
+                if constexpr (!MODEL) return launch_trace_<MODE, FAST, MODEL, CAN_PAGE, false>(TRACE_ARGS);
+        }
+        if (cross) return launch_trace_<MODE, FAST, MODEL, false, true>(TRACE_ARGS);
+        if constexpr (!MODEL) return launch_trace_<MODE, FAST, MODEL, false, false>(TRACE_ARGS);
+        return 1;
+#undef TRACE_ARGS
+}
+
+/* the crossings the passes listed (their number is on the device: a grid for
+ * all of n, striding over whatever there is) */
+template <int MODE, bool FAST>
+static int launch_cross(struct tamd_view view, long n, double * pos, const double * dir, int * index,
+    double * length, int * n_steps, CrossList cross, Paging pg, ull * stats)
+{
+        constexpr bool CAN_PAGE = (MODE != TAMD_MODE_ONE_MAP);
+        const bool paged = CAN_PAGE && (pg.faulted != nullptr);
+        const void * kernel = paged ? (const void *)k_cross<MODE, FAST, CAN_PAGE> :
+                                      (const void *)k_cross<MODE, FAST, false>;
+        long blocks = (long)g_cus * trace_blocks_per_cu(kernel);
+        const long useful = (n + 255) / 256;
+        if (blocks > useful) blocks = useful;
+        if (paged)
+                hipLaunchKernelGGL((k_cross<MODE, FAST, CAN_PAGE>), dim3((unsigned)blocks), dim3(256), 0,
+                    g_stream, view, pos, dir, index, length, n_steps, cross, pg, stats);
+        else
+                hipLaunchKernelGGL((k_cross<MODE, FAST, false>), dim3((unsigned)blocks), dim3(256), 0,
+                    g_stream, view, pos, dir, index, length, n_steps, cross, pg, stats);
+        LAUNCH_CHECK("k_cross");
+        return 0;
 }
 
 static int env_int(const char * name, int fallback)
@@ -3202,12 +3408,6 @@ static int park_threshold(int mode, long n)
         if (value == -2) value = env_int("TURTLE_AMD_PARK", -1);
         if (value >= 0) return value;
         return (mode == TAMD_MODE_GENERIC) ? 512 : 32;
-}
-static int park_threshold_2(void)
-{
-        static int value = -1;
-        if (value < 0) value = max(0, env_int("TURTLE_AMD_PARK2", 0));
-        return value;
 }
 /* Few in a small batch, where the launch waits for single rays in all-but-empty
  * waves (C2, 1 M rays: 8 lanes 6.85 ms, 32 lanes 7.08, 64 lanes 7.4); more in a large
@@ -3236,58 +3436,75 @@ static int drain_lanes(void)
 /* One round of a trace: all the rays (pg.ids == NULL), or the ones the last
  * round listed because they needed a tile (they carry on from the arrays).
  *
- * Fast arithmetic runs in two phases: A steps every ray by the closed form up to
+ * The passes step; a ray whose step crossed a boundary goes on a list (CROSS, see
+ * trace_body) and k_cross locates the crossings at the end, packed.
+ * Fast arithmetic steps in two passes: A takes every ray by the closed form up to
  * park_threshold() steps (32, or 512: see there) and hands over what is left; B
- * takes those to the end on their lines.  A ray changes phase at a fixed step
- * count, or (below it, when A's queue ran dry) where its arithmetic does not
- * depend on the phase: see LINED.  A third phase C for the rays beyond a second
- * threshold (TURTLE_AMD_PARK2; a few to a wave, on an otherwise empty chip) is
- * wired in but off: measured on C2, every threshold from 256 to 2 048 made the
- * trace slower (6.9-7.8 ms against 6.0 ms) -- what phase B waits for is not its
- * one longest ray but the medium ones (1 000-3 000 steps, a thousand of C2's
- * million) that happen to be drawn from the queue last. */
+ * takes those to their crossing on their lines.  A ray changes pass at a fixed
+ * step count, or (below it, when A's queue ran dry) where its arithmetic does not
+ * depend on the pass: see LINED.  (A third pass for the rays beyond a second
+ * threshold, a few to a wave on an otherwise empty chip, was wired in until round
+ * 3 and always off: on C2 every threshold from 256 to 2 048 made the trace slower,
+ * 6.9-7.8 ms against 6.0 ms.)
+ * Without scratch for the lists (`parked` NULL: a batch beyond 2^31 rays) there
+ * is one pass, which bisects in place. */
 template <int MODE>
 static int run_trace(struct tamd_view view, long n, double * pos, const double * dir,
     int max_steps, int * index, double * length, int * n_steps, int flags, int * parked,
-    Paging pg, ull * stats, ull * queue)
+    double * cross_ds, Paging pg, ull * stats, ull * queue)
 {
         const bool again = (pg.ids != nullptr);
         if (again) flags |= TRACE_CARRY_MEDIUM;
         const int resume = again ? 2 : 0;
-        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, resume, pg, 0, 0, kChunk, creep_lanes(n), dense_go() };
-        if (g_math_strict || !view.fast_ok)
-                return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
-                    length, n_steps, flags, one, stats, queue);
-        const int park = park_threshold(MODE, n);
-        if ((parked == nullptr) || (park <= 0) || (max_steps <= park) || (length == nullptr) ||
-            (n_steps == nullptr))
+        const bool strict = g_math_strict || !view.fast_ok;
+        /* lists: parked[0 .. n) from A to B, parked[n .. 3n) the crossings; counters:
+         * queue[0], [1]: the work queues of A, B; queue[2], [3]: the lengths of the lists */
+        const bool listed = (parked != nullptr) && (cross_ds != nullptr) && (length != nullptr) &&
+            (n_steps != nullptr);
+        const CrossList none = { nullptr, nullptr, nullptr, nullptr };
+        const CrossList cross = { parked + n, cross_ds, queue + 3, parked + 2 * n };
+        const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, resume, pg, 0, 0, kChunk,
+                creep_lanes(n), dense_go(), listed ? cross : none };
+        if (!listed) {
+                if (strict)
+                        return launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index,
+                            length, n_steps, flags, one, stats, queue);
                 return launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index,
                     length, n_steps, flags, one, stats, queue);
-        /* lists: parked[0 .. n) from A to B, parked[n .. 2n) from B to C; counters:
-         * queue[0], [1], [3]: the work queues of A, B, C; queue[2], [4]: the lists */
-        int park2 = park_threshold_2();
-        if ((park2 <= park) || (max_steps <= park2)) park2 = 0;
+        }
+        if (strict) {
+                if (launch_trace<MODE, false, false>(view, n, again, pos, dir, max_steps, index, length,
+                        n_steps, flags, one, stats, queue))
+                        return 1;
+                return launch_cross<MODE, false>(view, n, pos, dir, index, length, n_steps, cross, pg, stats);
+        }
+        const int park = park_threshold(MODE, n);
+        if ((park <= 0) || (max_steps <= park)) {
+                if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
+                        n_steps, flags, one, stats, queue))
+                        return 1;
+                return launch_cross<MODE, true>(view, n, pos, dir, index, length, n_steps, cross, pg, stats);
+        }
         const PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, resume, pg, drain_lanes(), 0,
-                kChunk, creep_lanes(n), dense_go() };
+                kChunk, creep_lanes(n), dense_go(), cross };
         if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
                 n_steps, flags, a, stats, queue))
                 return 1;
-        const PhaseIO b = { parked, queue + 2, park2 ? parked + n : nullptr, queue + 4, park2, 1, pg,
-                0, park, kChunk, creep_lanes(n), dense_go() };
+        const PhaseIO b = { parked, queue + 2, nullptr, nullptr, 0, 1, pg, 0, park, kChunk,
+                creep_lanes(n), dense_go(), cross };
         if (launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
                 n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1))
                 return 1;
-        if (park2 == 0) return 0;
-        const PhaseIO c = { parked + n, queue + 4, nullptr, nullptr, 0, 1, pg, 0, park, kTailChunk, creep_lanes(n), dense_go() };
-        return launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
-            n_steps, flags | TRACE_CARRY_MEDIUM, c, stats, queue + 3);
+        return launch_cross<MODE, true>(view, n, pos, dir, index, length, n_steps, cross, pg, stats);
 }
 
-/* queue: five counters (see run_trace); parked: room for 2 n ray ids.  pg: the round of a paged geometry (paging.c), all NULL otherwise; the
- * counters in `stats` add up over the rounds of a call. */
+/* queue: five counters (see run_trace); parked: room for 3 n ray ids and cross_ds
+ * for n doubles (the lists of the passes), or NULL.  pg: the round of a paged
+ * geometry (paging.c), all NULL otherwise; the counters in `stats` add up over the
+ * rounds of a call. */
 extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
-    int flags, int * parked, struct tamd_paging pg, unsigned long long * stats,
+    int flags, int * parked, double * cross_ds, struct tamd_paging pg, unsigned long long * stats,
     unsigned long long * queue)
 {
         if (tamd_dev_init()) return 1;
@@ -3306,12 +3523,12 @@ extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
         const int carry = (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0;
         if (view.mode == TAMD_MODE_ONE_MAP)
                 return run_trace<TAMD_MODE_ONE_MAP>(view, n, pos, dir, max_steps, index, length,
-                    n_steps, carry, parked, pg, stats, queue);
+                    n_steps, carry, parked, cross_ds, pg, stats, queue);
         if (view.mode == TAMD_MODE_ONE_STACK)
                 return run_trace<TAMD_MODE_ONE_STACK>(view, n, pos, dir, max_steps, index, length,
-                    n_steps, carry, parked, pg, stats, queue);
+                    n_steps, carry, parked, cross_ds, pg, stats, queue);
         return run_trace<TAMD_MODE_GENERIC>(view, n, pos, dir, max_steps, index, length, n_steps,
-            carry, parked, pg, stats, queue);
+            carry, parked, cross_ds, pg, stats, queue);
 }
 
 /* n single steps with a direction, in two passes (see k_step); cross_ray /
@@ -3325,7 +3542,7 @@ extern "C" int tamd_k_step_dir(struct tamd_view view, long n, double * pos,
         if (pg.ids == nullptr) HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
         HIP_TRY(hipMemsetAsync(queue, 0, 3 * sizeof(ull), g_stream));
         if (n <= 0) return 0;
-        const CrossList cross = { cross_ray, (cross_ray != nullptr) ? cross_ds : nullptr, queue + 2 };
+        const CrossList cross = { cross_ray, (cross_ray != nullptr) ? cross_ds : nullptr, queue + 2, nullptr };
         const StepWalk no_walk = { 0, 0, 0, 0, nullptr, nullptr };
         return run_step(view, n, pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg,
             stats, no_walk);
@@ -3343,7 +3560,7 @@ extern "C" int tamd_k_step_walk(struct tamd_view view, long n, double * pos, dou
         /* (stats add up over the generations of a walk: the caller zeroes them) */
         HIP_TRY(hipMemsetAsync(queue, 0, 3 * sizeof(ull), g_stream));
         if (n <= 0) return 0;
-        const CrossList cross = { cross_ray, cross_ds, queue + 2 };
+        const CrossList cross = { cross_ray, cross_ds, queue + 2, nullptr };
         const StepWalk walk = { 1, seed, stream, first, length, steps };
         return run_step(view, n, pos, nullptr, nullptr, nullptr, alt, elev, nullptr, index,
             TURTLE_AMD_STEP_RESUME, cross, pg, stats, walk);

@@ -197,12 +197,14 @@ int tamd_k_step(struct tamd_view view, long n, double * pos,
 /* stats: 4 x uint64 on the device (rays, steps, samples, capped); queue:
  * TAMD_TRACE_COUNTERS x uint64 (work queues and list lengths of the passes of a
  * fast trace: see run_trace in device.hip); both zeroed by the launcher.
- * parked: int[3 n] scratch for the lists of rays handed from pass to pass, or
- * NULL for a single-pass launch. */
+ * parked: int[3 n] and cross_ds: double[n], scratch for the lists of rays handed
+ * from pass to pass (the long rays; the rays that crossed a boundary, for
+ * k_cross), or NULL for a single-pass launch that bisects in place; with them,
+ * length and n_steps must not be NULL. */
 #define TAMD_TRACE_COUNTERS 24
 int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length,
-    int * n_steps, int flags, int * parked, struct tamd_paging pg,
+    int * n_steps, int flags, int * parked, double * cross_ds, struct tamd_paging pg,
     unsigned long long * stats, unsigned long long * queue);
 /* n single steps with a direction: the step kernel lists the rays that crossed
  * a boundary (cross_ray / cross_ds: scratch for n entries each, or NULL to

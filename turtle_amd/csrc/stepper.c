@@ -583,10 +583,14 @@ enum turtle_return turtle_stepper_position_n(struct turtle_stepper * stepper, lo
         return TURTLE_RETURN_SUCCESS;
 }
 
-/* Grow-only scratch of the batch calls: 3 n ints (the rays a trace hands from
- * pass to pass / the rays a batch of steps defers to its bisection pass)
- * followed by n doubles.  0 if it holds n entries; 1 if n is beyond an int
- * (the caller does without); parked_capacity < 0 after a device failure. */
+/* Grow-only scratch of the batch calls: 4 n ints (the rays a trace hands from
+ * pass to pass, the rays whose step crossed a boundary and what they found
+ * there / the rays a batch of steps defers to its bisection pass; the step
+ * counts of a trace whose caller wants none) followed by 3 n doubles (the step a
+ * ray that waits for a tile was about to take; the crossing steps; the path
+ * lengths of a trace whose caller wants none).  0 if it holds n entries; 1 if n
+ * is beyond an int (the caller does without); parked_capacity < 0 after a device
+ * failure. */
 static int tamd_stepper_scratch(struct turtle_stepper * stepper, long n)
 {
         if (n >= 2147483647L) return 1;
@@ -600,9 +604,9 @@ static int tamd_stepper_scratch(struct turtle_stepper * stepper, long n)
                 tamd_dev_free(stepper->d_parked);
                 stepper->d_parked = NULL;
         }
-        const size_t ints = (((size_t)n * 3 * sizeof(int) + 255) / 256) * 256; /* three lists */
+        const size_t ints = (((size_t)n * 4 * sizeof(int) + 255) / 256) * 256;
         stepper->parked_capacity = 0;
-        if (tamd_dev_malloc((void **)&stepper->d_parked, ints + (size_t)n * sizeof(double))) {
+        if (tamd_dev_malloc((void **)&stepper->d_parked, ints + (size_t)n * 3 * sizeof(double))) {
                 stepper->parked_capacity = -1;
                 return 1;
         }
@@ -811,9 +815,11 @@ static int trace_round(struct turtle_stepper * stepper, struct tamd_paging pg, i
         struct trace_args * a = p;
         (void)round;
         pg.tentative = a->scratch ? stepper->d_scratch_ds : NULL;
+        /* the lists of the passes; the packed media of the crossings hold 16 bits each */
+        const int listed = a->scratch && (stepper->n_layers < 65000) && (stepper->n_data < 65000);
         return tamd_k_trace(stepper->view, a->n, a->pos, a->dir, a->max_steps, a->index, a->length,
-            a->n_steps, a->flags, a->scratch ? stepper->d_parked : NULL, pg, stepper->d_stats,
-            stepper->d_stats + 4);
+            a->n_steps, a->flags, listed ? stepper->d_parked : NULL,
+            listed ? stepper->d_scratch_ds + a->n : NULL, pg, stepper->d_stats, stepper->d_stats + 4);
 }
 
 enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long n,
@@ -838,21 +844,15 @@ enum turtle_return turtle_stepper_trace_n(struct turtle_stepper * stepper, long 
             tamd_stage_out(&st, n_steps, n * sizeof(int), &args.n_steps))
                 return TAMD_RAISE_DEVICE();
         /* a ray that waits for a tile keeps its path length and step count in
-         * these arrays: over paged stacks they exist even if the caller has none */
+         * these arrays, and so does a ray handed from pass to pass: they exist
+         * even if the caller has none -- which outputs a caller asks for changes
+         * neither the kernels that run nor a bit of the others */
         if (stepper_is_paged(stepper) && !args.scratch)
                 return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR,
                     "a batch this large cannot run over stacks with tiles left to page in");
-        if (stepper_is_paged(stepper) && (n > 0) && ((args.length == NULL) || (args.n_steps == NULL))) {
-                if (space == TURTLE_AMD_DEVICE) {
-                        /* nothing was staged: the arena is neither sized nor reset yet */
-                        void * all;
-                        tamd_scratch_reset();
-                        if (tamd_scratch_get(&all, nb + n * sizeof(int) + 1024)) return TAMD_RAISE_DEVICE();
-                        tamd_scratch_reset();
-                }
-                if (((args.length == NULL) && tamd_scratch_get(&args.length, nb)) ||
-                    ((args.n_steps == NULL) && tamd_scratch_get(&args.n_steps, n * sizeof(int))))
-                        return TAMD_RAISE_DEVICE();
+        if (args.scratch && (n > 0)) {
+                if (args.length == NULL) args.length = stepper->d_scratch_ds + 2 * n;
+                if (args.n_steps == NULL) args.n_steps = stepper->d_parked + 3 * n;
         }
         char message[4200];
         const int rc = stepper_rounds(stepper, n, &trace_round, &args, message, sizeof(message));
