@@ -24,12 +24,12 @@ i = d.index(old)
 d = d[:i] + "        unsigned long long c_[24] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};\n        const unsigned long long span0_ = __builtin_amdgcn_s_memtime();\n        unsigned long long dry_ = 0;\n" + d[i:]
 sub("                                const bool stopped = (ray >= 0) & !going;\n",
     "                                c_[sparse ? 2 : 3] += 1;\n                                const bool stopped = (ray >= 0) & !going;\n")
-sub("                                                my_samples++;\n                                                ds = ds_next;",
-    "                                                my_samples++;\n                                                c_[sparse ? 4 : 5] += 1;\n                                                ds = ds_next;")
+sub("                                                count++;\n                                                /* d_step_length for one surface",
+    "                                                count++;\n                                                c_[sparse ? 4 : 5] += 1;\n                                                /* d_step_length for one surface")
 sub("                                        if (it == 0) creep_wait = kCreepBackoff;",
     "                                        if (it == 0) creep_wait = kCreepBackoff, c_[7] += 1;")
-sub("                        const bool in_rock = (m == 0); /* a lane's medium does not change in here */\n                        for (int it = 0; it < 4096; it++) {",
-    "                        const bool in_rock = (m == 0);\n                        if (!sparse) c_[6] += 1;\n"
+sub("                        const int count_in = count;\n                        for (int it = 0; it < 4096; it++) {",
+    "                        const int count_in = count;\n                        if (!sparse) c_[6] += 1;\n"
     "                        const unsigned long long lt0_ = __builtin_amdgcn_s_memtime();\n"
     "                        for (int it = 0; it < 4096; it++) {")
 sub("                const bool drain = !MODEL && (ph.park_after > 0) && exhausted && (ray >= 0) &&",
@@ -38,8 +38,8 @@ sub("                const bool drain = !MODEL && (ph.park_after > 0) && exhaust
     "                        c_[20] += ((ray >= 0) && !lined_) ? 1 : 0, c_[21] += ((ray >= 0) && (state == ST_BISECT)) ? 1 : 0,\n"
     "                        c_[22] += ((ray >= 0) && (state == ST_INIT)) ? 1 : 0;\n"
     "                const bool drain = !MODEL && (ph.park_after > 0) && exhausted && (ray >= 0) &&")
-sub("                                break;\n                        }\n                }\n",
-    "                                break;\n                        }\n                        c_[9] += __builtin_amdgcn_s_memtime() - lt0_;\n                }\n")
+sub("                                break;\n                        }\n                        my_samples += (ull)(count - count_in);",
+    "                                break;\n                        }\n                        c_[9] += __builtin_amdgcn_s_memtime() - lt0_;\n                        my_samples += (ull)(count - count_in);")
 sub("                /* ---- park over-long rays (phase A; whole wave takes part) ---- */",
     "                if (MODEL) c_[10] += __builtin_amdgcn_s_memtime() - gt0_;\n"
     "                /* ---- park over-long rays (phase A; whole wave takes part) ---- */")
@@ -47,22 +47,24 @@ sub("                                        f_line_relay<MODE>(v, ctx, qx, qy, 
     "                                        f_line_relay<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line, s, cache);\n                                        line.s = -t, c_[8] += 1;")
 sub("                                        relay_wait = ((n_need == 0) | now) ? 0 : waited + 1;",
     "                                        relay_wait = ((n_need == 0) | now) ? 0 : waited + 1;\n                                        c_[19] += (relay & now) ? 1 : 0, c_[23] += (relay & !now) ? 1 : 0;")
-sub("                                        going = going & (count + 1 < max_steps) & (fabs(sl) <= kLineRange) & interior;",
+sub("                                        double fx = hx - cx, fy = hy - cy;\n                                        if (going & (max(",
     """                                        if ((u == 0) && (ray >= 0)) {
                                                 c_[12] += 1;
                                                 c_[13] += (state != ST_STEP) ? 1 : 0;
                                                 c_[14] += ((state == ST_STEP) && !(lined_ & line.valid)) ? 1 : 0;
-                                                c_[15] += (going && !((count + 1 < max_steps) & (fabs(sl) <= kLineRange) & interior)) ? 1 : 0;
+                                                c_[15] += ((state == ST_STEP) && lined_ && line.valid && !going) ? 1 : 0;
                                         }
-                                        going = going & (count + 1 < max_steps) & (fabs(sl) <= kLineRange) & interior;""")
+                                        double fx = hx - cx, fy = hy - cy;
+                                        if (going & (max(""")
 sub("                                                const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);\n                                                const int ix = (int)tx, iy = (int)ty;",
     "                                                if (u == 0) c_[16] += 1;\n                                                const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);\n                                                const int ix = (int)tx, iy = (int)ty;")
-sub("                                        going = going & f_line_serves(line, sl, clearance) & same;",
-    """                                        if ((u == 0) && going) {
+sub("                                        const double s2 = sl * sl;\n                                        going = going &",
+    """                                        const double s2 = sl * sl;
+                                        if ((u == 0) && going) {
                                                 c_[17] += !f_line_serves(line, sl, clearance) ? 1 : 0;
-                                                c_[18] += !same ? 1 : 0;
+                                                c_[18] += !(__builtin_fma(sgn, t, 0.) > 0.) ? 1 : 0;
                                         }
-                                        going = going & f_line_serves(line, sl, clearance) & same;""")
+                                        going = going &""")
 sub("        block_tally(stats, my_rays, my_steps, my_samples, my_capped);\n}\n\n/* The least waves a SIMD the kernel must fit",
     """        if (MODEL && ((threadIdx.x & 63) == 0)) {
                 const unsigned w_ = (blockIdx.x * 4 + (threadIdx.x >> 6)) & 4095u;

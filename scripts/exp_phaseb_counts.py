@@ -21,6 +21,13 @@ st.add_map(tile, 0.0)
 lat, lon, az, el = sharding.rank_rays(n, 0, (45.0, 46.0), (3.0, 4.0))
 pos, _ = st.position(lat, lon, 500.0)
 d = TA.ecef_from_horizontal(lat, lon, az, el)
+# SUBSET=lo:hi:k -- only the first k rays whose step count is in [lo, hi] (a wave of medium rays alone)
+if os.environ.get("SUBSET"):
+    lo, hi, k = (int(x) for x in os.environ["SUBSET"].split(":"))
+    steps = st.trace(pos.copy(), d)["n_steps"]
+    ids = np.nonzero((steps >= lo) & (steps <= hi))[0][:k]
+    pos, d = np.ascontiguousarray(pos[ids]), np.ascontiguousarray(d[ids])
+    print(f"subset: {ids.size} rays of {lo}..{hi} steps")
 c = np.zeros(32, dtype=np.uint64)
 st.trace(pos.copy(), d)
 binding.lib().tamd_dev_cnt_read(c.ctypes.data_as(C.c_void_p), 1)

@@ -2142,16 +2142,27 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                          * guard as there) gets that tile from the directory too */
                         constexpr bool STACK = (MODE == TAMD_MODE_ONE_STACK);
                         const tamd_grid & g = STACK ? ctx.stack.proto : ctx.grid;
-                        constexpr double guard = STACK ? kSeamGuard : 1e-6;
-                        const double mx = (double)(g.nx - 1) - guard, my = (double)(g.ny - 1) - guard;
                         /* The cached cell, decoded once per entry (and after a trip that
                          * changed it): its origin, its node coordinates as doubles and its
                          * four elevations -- a step then needs no conversion between
                          * integers and doubles (a quarter of the rate of the other
                          * instructions, and on the chain).  Same values as f_grid_locate /
                          * f_grid_blend produce: for an interior point (double)(int)hx ==
-                         * trunc(hx), and the clamp of the cell index does nothing. */
+                         * trunc(hx), and the clamp of the cell index does nothing.
+                         * "Still in the cached cell" is asked of the fractions fx = hx - cx,
+                         * fy = hy - cy with a margin of `guard` -- g < f < 1 - g, as a test of f's
+                         * upper word against those of g and 1 - g -- so that a point that
+                         * passes is `interior` to the grid (or the tile: the guards of
+                         * f_grid_locate and f_stack_elevation) whichever cell it is in; the few
+                         * within the margin of a cell's edge take the way of a cell change,
+                         * which makes that test on the point itself. */
+                        constexpr double guard = STACK ? kSeamGuard : 1e-6;
+                        /* the upper word of guard, plus one; that of 1 - guard */
+                        constexpr unsigned lo_word = STACK ? 0x3e112e0cu : 0x3eb0c6f8u;
+                        constexpr unsigned span_words = (STACK ? 0x3fefffffu : 0x3feffffdu) - lo_word;
+                        const double mx = (double)(g.nx - 1) - guard, my = (double)(g.ny - 1) - guard;
                         double x0, y0, cx, cy, z00, z10, z01, z11;
+                        bool cached;
                         auto decode_nodes = [&]() {
                                 if (g.is_signed) {
                                         z00 = (double)(int16_t)(cell.lo & 0xffffu), z10 = (double)((int)cell.lo >> 16);
@@ -2166,7 +2177,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 z11 = (z11 - z10) - (z01 - z00), z10 = z10 - z00, z01 = z01 - z00;
                         };
                         auto decode_cell = [&]() {
-                                const bool cached = (cell.id != ~0u);
+                                cached = (cell.id != ~0u);
                                 const unsigned slot = STACK ? (cell.id >> 24) : 0u;
                                 const unsigned cell_index = STACK ? (cell.id & 0xffffffu) : cell.id;
                                 const unsigned tile_y = STACK ? slot / (unsigned)ctx.stack.nlon : 0u;
@@ -2174,65 +2185,80 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 x0 = STACK ? ctx.stack.lon0 + (int)tile_x * ctx.stack.dlon : g.x0;
                                 y0 = STACK ? ctx.stack.lat0 + (int)tile_y * ctx.stack.dlat : g.y0;
                                 const unsigned cell_iy = cached ? cell_index / (unsigned)g.nx : 0u;
+                                const unsigned cell_ix = cached ? cell_index - cell_iy * (unsigned)g.nx : 0u;
                                 cy = cached ? (double)cell_iy : -1.;
-                                cx = cached ? (double)(cell_index - cell_iy * (unsigned)g.nx) : -1.;
+                                cx = cached ? (double)cell_ix : -1.;
                                 decode_nodes();
                         };
                         decode_cell();
-                        const bool in_rock = (m == 0); /* a lane's medium does not change in here */
+                        /* The test of a lean step is SUFFICIENT for the step the general
+                         * iteration would accept, not equivalent to it -- a lane that fails
+                         * it has committed nothing and the general iteration decides: with
+                         * t = altitude - elevation and sgn = -1 in the rock, +1 above it,
+                         *   sgn t > tau                  => the line serves as to drift and
+                         *                                   truncation near the boundary (|t| > tau)
+                         *                                   AND the medium is the ray's;
+                         *   k4 min(max(|t|, 1), 2000) > s^4  => the line serves as to its reach,
+                         *                                   which is then below kLineRange too
+                         *                                   ((1.11e11 x 2000)^(1/4) = 3852 m at the
+                         *                                   equator, where k4 is largest);
+                         * and a step within kCreepUnroll of the cap is left to the general
+                         * iteration.  Two compares a step decide it where the reference's
+                         * tests, one by one, took a dozen and as many scalar instructions
+                         * between them: that chain is what a step of a lone wave waits for. */
+                        const double sgn = (m == 0) ? -1. : 1.; /* a lane's medium does not change in here */
+                        const int count_in = count;
                         for (int it = 0; it < 4096; it++) {
                                 /* no short-circuits below: every lane computes
                                  * everything (garbage is harmless, nothing is
                                  * committed on failure) and the tests are AND-ed */
-                                bool going = (ray >= 0) & (state == ST_STEP) & lined_ & line.valid &
-                                    (!STACK || (cell.id != ~0u)); /* a stack: the tile comes with a cached cell */
+                                bool going = (ray >= 0) & (state == ST_STEP) & lined_ & line.valid & cached &
+                                    (count + kCreepUnroll < max_steps);
 #pragma unroll
                                 for (int u = 0; u < kCreepUnroll; u++) {
                                         const double sl = line.s + ds;
                                         double lat, lon, alt;
                                         f_line_eval(line, sl, lat, lon, alt);
-                                        /* f_grid_locate without its rim fallback: a point
-                                         * within 1e-6 cell of the rim leaves the loop */
+                                        /* f_grid_locate without its rim fallback */
                                         const double hx = (lon - x0) * g.inv_dx;
                                         const double hy = (lat - y0) * g.inv_dy;
-                                        const bool interior =
-                                            (hx > guard) & (hx < mx) & (hy > guard) & (hy < my);
-                                        going = going & (count + 1 < max_steps) & (fabs(sl) <= kLineRange) & interior;
-                                        /* still in the cached cell <=> 0 <= hx - cx < 1 and the
-                                         * same in y: for a double that is "its upper word,
-                                         * unsigned, is below that of 1.0" (a negative one has
-                                         * the sign bit there, a NaN the exponent's) */
+                                        /* still in the cached cell, and not within `guard` of its
+                                         * edges <=> guard < hx - cx < 1 - guard and the same in y:
+                                         * for a double, "its upper word, unsigned, is in [that of
+                                         * guard + 1, that of 1 - guard)" (a negative one has the
+                                         * sign bit there, a NaN the exponent's) */
                                         double fx = hx - cx, fy = hy - cy;
-                                        if (going & ((d_upper_word(fx) >= 0x3ff00000u) | (d_upper_word(fy) >= 0x3ff00000u))) {
+                                        if (going & (max(d_upper_word(fx) - lo_word, d_upper_word(fy) - lo_word) >= span_words)) {
                                                 /* another cell of the same grid: what
                                                  * f_grid_elevation does on a cache miss */
                                                 const double tx = __builtin_trunc(hx), ty = __builtin_trunc(hy);
-                                                const int ix = (int)tx, iy = (int)ty;
-                                                const unsigned id = (unsigned)iy * (unsigned)g.nx + (unsigned)ix;
-                                                d_cell_fetch(STACK ? ctx.slots[cell.id >> 24] : g.nodes, g.nbx, ix, iy, cell.lo, cell.hi);
-                                                cell.id = STACK ? ((cell.id & 0xff000000u) | id) : id;
-                                                cx = tx, cy = ty;
-                                                fx = hx - tx, fy = hy - ty;
-                                                decode_nodes();
+                                                const int ix = (int)tx, iy = (int)ty; /* (NaN: 0) */
+                                                going = (hx > guard) & (hx < mx) & (hy > guard) & (hy < my);
+                                                if (going) {
+                                                        const unsigned id = (unsigned)iy * (unsigned)g.nx + (unsigned)ix;
+                                                        d_cell_fetch(STACK ? ctx.slots[cell.id >> 24] : g.nodes, g.nbx, ix, iy, cell.lo, cell.hi);
+                                                        cell.id = STACK ? ((cell.id & 0xff000000u) | id) : id;
+                                                        cx = tx, cy = ty;
+                                                        fx = hx - tx, fy = hy - ty;
+                                                        decode_nodes();
+                                                }
                                         }
                                         /* f_grid_blend */
                                         const double elevation = f_patch(z00, z10, z01, z11, fx, fy) + ctx.offset;
-                                        const double clearance = fabs(alt - elevation);
-                                        /* the medium of the sample, (elevation >= alt) ? 0 : 1,
-                                         * is the ray's (0 or 1 over one surface) */
-                                        const bool same = ((elevation >= alt) == in_rock);
-                                        going = going & f_line_serves(line, sl, clearance) & same;
-                                        /* d_step_length for one surface: both of its
-                                         * cases are |alt - elevation| */
-                                        const double ds_next = fmax(clearance * v.slope, v.resolution);
+                                        const double t = alt - elevation;
+                                        const double clearance = fabs(t);
+                                        const double s2 = sl * sl;
+                                        going = going & (__builtin_fma(sgn, t, -line.tau) > 0.) &
+                                            (__builtin_fma(line.k4, fmin(fmax(clearance, 1.), 2000.), -(s2 * s2)) > 0.);
                                         if (going) {
                                                 bx = bx + dx * ds, by = by + dy * ds, bz = bz + dz * ds;
                                                 line.tau = line.tau + kLineDrift;
-                                                line.s = sl;
+                                                line.s = line.s + ds; /* == sl */
                                                 len = len + ds;
                                                 count++;
-                                                my_samples++;
-                                                ds = ds_next;
+                                                /* d_step_length for one surface: both of its
+                                                 * cases are |alt - elevation| */
+                                                ds = fmax(clearance * v.slope, v.resolution);
                                         }
                                 }
                                 const bool stopped = (ray >= 0) & !going;
@@ -2252,6 +2278,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 }
                                 break;
                         }
+                        my_samples += (ull)(count - count_in); /* a lean step is a sample */
                 }
 
                 /* `drain`: once the queue is dry a wave of phase A hands its rays over
