@@ -1242,6 +1242,17 @@ __device__ __forceinline__ double f_bracket_point(double ds0, double ds1, double
         return t;
 }
 
+/* b + d t, a ray's next position [ref stepper.c:824, :862-863].  The reference rounds
+ * the product and then the sum; the fast arithmetic of a trace fuses them.  The
+ * sum's rounding (an ulp of 6.4e6 m: 9e-10 m) is what accumulates into the drift
+ * that kLineDrift prices, the same either way; the product's (1e-16 of the step)
+ * changes which way the sum rounds once in 1e7 steps. */
+template <bool FAST>
+__device__ __forceinline__ double d_along(double b, double d, double t)
+{
+        return FAST ? __builtin_fma(d, t, b) : b + d * t;
+}
+
 /* [ref stepper.c:799-813] tentative step length from the last sample */
 __device__ __forceinline__ double d_step_length(
     const tamd_view & v, double alt, double e0, double e1, int m)
@@ -2084,7 +2095,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                         fail = (state != ST_STEP) || (count + 1 >= max_steps) || !lined_;
                                         if (!fail) {
                                                 const double sl = line.s + ds;
-                                                qx = bx + dx * ds, qy = by + dy * ds, qz = bz + dz * ds;
+                                                qx = d_along<FAST>(bx, dx, ds), qy = d_along<FAST>(by, dy, ds), qz = d_along<FAST>(bz, dz, ds);
                                                 /* a new line starts at q: B is at -ds on it */
                                                 if (f_sample_on_line<MODE>(v, ctx, qx, qy, qz, dx, dy,
                                                         dz, line, sl, s,
@@ -2251,7 +2262,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                         going = going & (__builtin_fma(sgn, t, -line.tau) > 0.) &
                                             (__builtin_fma(line.k4, fmin(fmax(clearance, 1.), 2000.), -(s2 * s2)) > 0.);
                                         if (going) {
-                                                bx = bx + dx * ds, by = by + dy * ds, bz = bz + dz * ds;
+                                                bx = d_along<FAST>(bx, dx, ds), by = d_along<FAST>(by, dy, ds), bz = d_along<FAST>(bz, dz, ds);
                                                 line.tau = line.tau + kLineDrift;
                                                 line.s = line.s + ds; /* == sl */
                                                 len = len + ds;
@@ -2301,7 +2312,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 t = FAST ? f_bracket_point(ds0, ds1, c0, c1, halvings & 0xffff) : 0.5 * (ds0 + ds1);
                         double qx = bx, qy = by, qz = bz;
                         if (state != ST_INIT) /* B + d*0 == B, but d may be garbage */
-                                qx = bx + dx * t, qy = by + dy * t, qz = bz + dz * t;
+                                qx = d_along<FAST>(bx, dx, t), qy = d_along<FAST>(by, dy, t), qz = d_along<FAST>(bz, dz, t);
 
                         Sample s;
                         if (LINED) {
@@ -2454,7 +2465,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                     (!(ds1 - ds0 > 1E-08) | ((halvings & 0xffff) > 1200));
                         }
                         if (located) { /* [ref stepper.c:861-863] */
-                                bx = bx + dx * ds1, by = by + dy * ds1, bz = bz + dz * ds1;
+                                bx = d_along<FAST>(bx, dx, ds1), by = d_along<FAST>(by, dy, ds1), bz = d_along<FAST>(bz, dz, ds1);
                                 len += ds + ds1;
                                 count++;
                                 m = bm, k = bk;
@@ -2623,7 +2634,7 @@ __global__ void __launch_bounds__(256) k_cross(tamd_view v, double * __restrict_
                         while ((fault.centre < 0) && (ds1 - ds0 > 1E-08) && (taken <= 1200)) {
                                 const double t = FAST ? f_bracket_point(ds0, ds1, c0, c1, taken) :
                                                         0.5 * (ds0 + ds1);
-                                const double qx = px + dx * t, qy = py + dy * t, qz = pz + dz * t;
+                                const double qx = d_along<FAST>(px, dx, t), qy = d_along<FAST>(py, dy, t), qz = d_along<FAST>(pz, dz, t);
                                 Sample s2;
                                 if (FAST) {
                                         if (!f_line_try<MODE>(v, ctx, line, at + t, s2, cache, true)) {
@@ -2657,7 +2668,8 @@ __global__ void __launch_bounds__(256) k_cross(tamd_view v, double * __restrict_
                                 pos[3 * r] = px - dx * ds, pos[3 * r + 1] = py - dy * ds, pos[3 * r + 2] = pz - dz * ds;
                                 pg.tentative[r] = ds;
                         } else { /* [ref stepper.c:861-863] */
-                                pos[3 * r] = px + dx * ds1, pos[3 * r + 1] = py + dy * ds1, pos[3 * r + 2] = pz + dz * ds1;
+                                pos[3 * r] = d_along<FAST>(px, dx, ds1), pos[3 * r + 1] = d_along<FAST>(py, dy, ds1),
+                                pos[3 * r + 2] = d_along<FAST>(pz, dz, ds1);
                                 index[2 * r] = bm, index[2 * r + 1] = bk;
                                 length[r] = length[r] + (ds + ds1);
                                 n_steps[r] = n_steps[r] + 1;
