@@ -20,6 +20,7 @@ from oracle import ffi as O
 
 import amd_build as B
 import terrains as T
+from turtle_amd import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -192,10 +193,36 @@ def test_hgt_tile_traces(golden, tmp_path, math):
     assert np.abs(pos - g["position"]).max() < 5e-9
     t = st.trace(g["position"].copy(), g["direction"])
     worst = check_trace(t, g["r0_index"], g["r0_length"], g["r0_n_steps"],
-                        "3601^2 tile vs reference", allow=2)
+                        "3601^2 tile vs reference")
     print(f"hgt 10k rays: worst relative path-length difference {worst:.2e}")
     st.destroy()
     m.destroy()
+
+
+def test_c3_seams_of_full_size_tiles(golden, tmp_path, math):
+    """C3's shape at full tile size: a stack of 3601^2 tiles, rays that start
+    within 0.01 degree of a seam and cross it, run along it or leave through the rim --
+    against the REFERENCE's own trace (G11), no ray set apart."""
+    g = golden("c3_seam")
+    stack = B.mosaic(tmp_path, [tuple(t) for t in g["tiles"]], synth.HGT_N)
+    st = TA.Stepper()
+    st.add_stack(stack, 0.0)
+    pos, di = st.position(g["lat"], g["lon"], 300.0)
+    assert (di == 0).all() and np.abs(pos - g["position"]).max() < 5e-9
+    t = st.trace(g["position"].copy(), g["direction"])
+    check_trace(t, g["t_index"], g["t_length"], g["t_n_steps"], "2x2 mosaic of 3601^2 tiles")
+    assert np.abs(t["position"] - g["t_position"]).max() < 1e-5  # (paths of up to 20 km)
+    # the same through a stack that pages: two tiles resident at a time
+    paged = TA.Stack(str(tmp_path / "mosaic"), 2)
+    sp = TA.Stepper()
+    sp.add_stack(paged, 0.0)
+    tp = sp.trace(g["position"].copy(), g["direction"])
+    check_trace(tp, g["t_index"], g["t_length"], g["t_n_steps"], "the same, two tiles resident")
+    assert sp.rounds > 1 and paged.resident <= 2
+    sp.destroy()
+    paged.destroy()
+    st.destroy()
+    stack.destroy()
 
 
 def test_stack_directory(golden, tmp_path, math):
@@ -216,7 +243,7 @@ def test_stack_directory(golden, tmp_path, math):
     pos, di = st.position(g["ray_lat"], g["ray_lon"], 300.0)
     assert (di == 0).all() and np.abs(pos - g["position"]).max() < 5e-9
     t = st.trace(g["position"].copy(), g["direction"])
-    check_trace(t, g["t_index"], g["t_length"], g["t_n_steps"], "2x2 mosaic", allow=1)
+    check_trace(t, g["t_index"], g["t_length"], g["t_n_steps"], "2x2 mosaic")
     st.destroy()
     stack.destroy()
     one = B.mosaic(tmp_path / "one", [(45, 3)], n)
@@ -264,7 +291,7 @@ def test_stack_rim_and_seams(tmp_path, math):
     mine2 = st.step(mine["position"], d, resume=mine)
     ref2 = geo.step(ref["position"], d)
     same = mine2["index"][:, 0] == ref2["index"][:, 0]
-    assert (~same).sum() <= 2, np.flatnonzero(~same)[:10]
+    assert (~same).sum() == 0, np.flatnonzero(~same)[:10]
     ok = same & (ref2["index"][:, 0] >= 0)
     assert np.abs(mine2["step"][ok] - ref2["step"][ok]).max() < 1e-6 * ref2["step"][ok].max()
     st.destroy()
@@ -463,7 +490,7 @@ def test_oracle_agrees_on_fresh_rays(math):
     d = O.ecef_from_horizontal(lat, lon, az, el)
     ref = geo.trace(pos0, d, threads=4)
     t = st.trace(pos0.copy(), d)
-    check_trace(t, ref["index"], ref["length"], ref["n_steps"], "fresh rays vs oracle", allow=1)
+    check_trace(t, ref["index"], ref["length"], ref["n_steps"], "fresh rays vs oracle")
     # max_steps cap and zero-step edge cases
     t = st.trace(pos0.copy(), d, max_steps=7)
     r7 = geo.trace(pos0, d, max_steps=7)
@@ -552,14 +579,21 @@ def test_long_rays_other_quadrants(where, math):
     ref = geo.trace(pos0, d, threads=4)
     t = st.trace(pos0.copy(), d)
     assert (ref["n_steps"] > 512).sum() > 50, "the recipe no longer reaches the second phase"
-    # These rays skim the ground for up to 1e5 steps: the most extreme of them
-    # amplify a 1e-9 m difference in one sample to centimetres (the strict
-    # arithmetic too: 2.5e-2 m on one of them).  Same rule as the full-size test:
-    # a few grazing rays may miss the bar, by no more than a few minimum steps.
+    # Zero tolerance, with ONE kind of ray set apart and named: a ray that never
+    # reaches a boundary and stops at the cap (max_steps = 100 000; south-west has
+    # one, ray 904: el = -0.795 deg, 28 951 m).  Its "path length" is no distance to
+    # an intersection but the sum of 1e5 clearance-sized steps along the ground,
+    # each fed by the sample before it: a 1e-9 m difference in one sample grows to
+    # centimetres (the STRICT arithmetic, which differs from the reference by OCML's
+    # last ulp in sin/cos only, ends 2.5e-2 m = 8.7e-7 off on it; FAST 4.5e-2 m =
+    # 1.6e-6; round 2's kernels the same to the digit).  For such a ray the bar is:
+    # same medium, same (capped) step count, 1e-5 on the sum.
     rel = np.abs(t["length"] - ref["length"]) / np.maximum(ref["length"], 1e-300)
-    grazing = (t["index"][:, 0] != ref["index"][:, 0]) | (rel > REL)
-    assert grazing.sum() <= 2, f"{where}: {int(grazing.sum())} rays off the bar"
-    assert np.abs(t["length"] - ref["length"])[grazing].max(initial=0.0) < 0.1
+    capped = ref["n_steps"] >= 100000
+    assert capped.sum() <= 1 and np.array_equal(t["n_steps"][capped], ref["n_steps"][capped])
+    assert np.array_equal(t["index"][capped], ref["index"][capped]) and (rel[capped] < 1e-5).all()
+    grazing = ((t["index"][:, 0] != ref["index"][:, 0]) | (rel > REL)) & ~capped
+    assert grazing.sum() == 0, f"{where}: {int(grazing.sum())} rays off the bar"
     ok = ~grazing
     assert (np.abs(t["n_steps"] - ref["n_steps"])[ok] <= 1).all()
     print(f"{where}: {int((ref['n_steps'] > 512).sum())} rays beyond 512 steps (max "
@@ -619,7 +653,7 @@ def test_scattering_walk_against_oracle(math):
         ref_total += o["step"]
     # crossing the surface at random angles 120 000 times: a handful of rays may
     # be classified differently when they land within 1e-9 m of it
-    assert flips <= 3, flips
+    assert flips == 0, flips
     st.destroy()
     m.destroy()
 
@@ -664,7 +698,7 @@ def test_scatter_n_is_the_step_loop(math, tmp_path):
             assert np.array_equal(w["altitude"][inside], state["altitude"][inside])
         else:
             same = (w["index"][:, 0] == state["index"][:, 0]) & (w["steps"] == moved)
-            assert (~same).sum() <= 3, int((~same).sum())
+            assert (~same).sum() == 0, int((~same).sum())
             assert np.abs(w["position"][same] - state["position"][same]).max() < 1e-6
             assert np.abs(w["length"][same] - total[same]).max() < 1e-6
         w2 = st.scatter(pos.copy(), 4242, 10, first_ray=17)
@@ -877,7 +911,7 @@ def test_scatter_over_a_stack_against_the_oracle(math, tmp_path):
     ref_medium = np.where(alive, o["index"][:, 0], -1)
     same = (w["index"][:, 0] == ref_medium) & (w["steps"] == steps)
     # a ray that lands on the other side of a surface by 1e-9 m has diverged for good
-    assert (~same).sum() <= 3, int((~same).sum())
+    assert (~same).sum() == 0, int((~same).sum())
     assert np.abs(w["position"][same] - ref_pos[same]).max() < 1e-5
     rel = np.abs(w["length"][same] - total[same]) / np.maximum(total[same], 1e-300)
     assert rel.max() <= REL, rel.max()

@@ -59,11 +59,12 @@ def test_c2_full_size_against_cpu_oracle(c2, mode):
           f"the others: max |dL|/L = {rel[ok].max():.2e}, median {np.median(rel[ok]):.1e}; "
           f"rays with a different step count: {int((dsteps != 0).sum())}, "
           f"steps GPU {int(t['n_steps'].sum())} CPU {int(ref['n_steps'].sum())}")
-    assert grazing.size <= N * 1e-5
+    assert grazing.size == 0
     assert rel[ok].max() <= 1e-6
     # a grazing ray ends within a few minimum steps (1e-2 m) of the reference's end
     assert np.abs(t["length"] - ref["length"])[grazing].max(initial=0.) < 0.1
-    assert (dsteps[ok] <= 2).all() and (dsteps != 0).mean() < 1e-3
+    # (logged: 4 rays of the million in fast arithmetic, 1 in strict, take a step more or less)
+    assert (dsteps[ok] <= 1).all() and (dsteps != 0).sum() <= 10
 
 
 def test_c2_properties(c2):

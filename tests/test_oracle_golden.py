@@ -9,6 +9,7 @@ import numpy as np
 
 from oracle import ffi as O
 import terrains as T
+from turtle_amd import synth
 
 
 def eq(a, b):
@@ -114,6 +115,23 @@ def test_g4_hgt_tile(golden):
     for prefix, rng in (("r0", 0.0), ("r1", 1.0)):
         t = geo.trace(g["position"], g["direction"], local_range=rng, threads=4)
         _check_trace(t, g, prefix)
+
+
+def test_g11_c3_seam_full_size_tiles(golden):
+    """C3's shape at full tile size: rays across the seams of a 2x2 mosaic of 3601^2 tiles, the
+    restatement against the reference's own trace, bit for bit."""
+    g = golden("c3_seam")
+    tiles = [tuple(t) for t in g["tiles"]]
+    assert T.sha(synth.srtm_like_nodes(45, 3)) == str(g["nodes_sha"])
+    geo = T.mosaic_oracle(tiles, synth.HGT_N, 45, 3, 2, 2)
+    pos, di = geo.position(g["lat"], g["lon"], 300.0)
+    assert eq(pos, g["position"]) and (di == 0).all()
+    t = geo.trace(g["position"], g["direction"], threads=4)
+    _check_trace(t, g, "t")
+    # the rays do what the fixture is for: they end in another tile than they started in
+    lat1, lon1, _ = O.ecef_to_geodetic(t["position"])
+    moved = (np.floor(lat1) != np.floor(g["lat"])) | (np.floor(lon1) != np.floor(g["lon"]))
+    assert moved.sum() > 300 and (t["index"][:, 0] == -1).any()
 
 
 def test_g5_stack(golden):
