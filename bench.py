@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_CLOCK_HZ = 2.4e9       # MI355X peak engine clock (MI355X_MICROARCH.md)
-TRACE_KERNEL = "k_trace (phase A: every ray by the closed form up to its hand-over step, 32 or 512; phase B: the rest on their lines)"
+TRACE_KERNEL = "k_trace (phase A: every ray by the closed form up to its hand-over step, 32 or 512; phase B: the rest on their lines) + k_cross (every crossing, packed)"
 STEP_KERNELS = "k_step_fast + k_bisect per generation (single steps, directions drawn in the kernel)"
 WALK_KERNEL = "k_walk (a ray's whole walk in one launch: state in registers, directions drawn in the kernel)"
 SEED = 0x5EED2026
@@ -107,34 +107,73 @@ def host_cores():
     return n
 
 
+def node_barrier(env):
+    """every rank of the job (they share the node: one process per GPU)"""
+    if env["world"] > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
 class Terrain:
-    """The synthetic tiles of a workload, written as .hgt files and loaded through
-    the C API; the node arrays are kept for the CPU checker."""
+    """The synthetic tiles of a workload as files -- SRTM's .hgt, or (C5: `fmt` "tif")
+    the GeoTIFF-16 tiles ASTER-GDEM2 ships -- written ONCE per node (local rank 0 writes,
+    the others wait at a barrier) and loaded by every rank through the C API; rank 0 keeps
+    the node arrays for the CPU checker."""
 
-    def __init__(self, TA, tiles, use_stack, rank, stack_size=0):
+    def __init__(self, TA, tiles, use_stack, env, stack_size=0, fmt="hgt"):
         from turtle_amd import synth
-        self.tiles, self.use_stack = tiles, use_stack
+        self.tiles, self.use_stack, self.env, self.fmt = tiles, use_stack, env, fmt
         lat0, lon0, nlat, nlon = tiles
-        self.tmp = tempfile.mkdtemp(prefix=f"turtle_bench_{rank}_")
-        cells = [(lat0 + i, lon0 + j) for i in range(nlat) for j in range(nlon)]
+        self.cells = [(lat0 + i, lon0 + j) for i in range(nlat) for j in range(nlon)]
+        # one directory for the job: every rank derives the same name
+        job = os.environ.get("MASTER_PORT", str(os.getpid())) if env["world"] > 1 else str(os.getpid())
+        self.tmp = os.path.join(tempfile.gettempdir(), f"turtle_bench_{job}_{lat0}_{lon0}_{nlat}x{nlon}_{fmt}")
+        self.nodes, self.hgt_dir = {}, None
+        name = synth.geotiff_name if fmt == "tif" else synth.hgt_name
+        if env["rank"] == 0:
+            shutil.rmtree(self.tmp, ignore_errors=True)
+            os.makedirs(self.tmp)
 
-        def make(cell):
-            nodes = synth.srtm_like_nodes(*cell)
-            with open(os.path.join(self.tmp, synth.hgt_name(*cell)), "wb") as f:
-                f.write(synth.hgt_bytes(nodes))
-            return cell, nodes
-        with concurrent.futures.ThreadPoolExecutor(max(1, min(8, host_cores()))) as pool:
-            self.nodes = dict(pool.map(make, cells))
+            def make(cell):
+                nodes = synth.srtm_like_nodes(*cell)
+                with open(os.path.join(self.tmp, name(*cell)), "wb") as f:
+                    if fmt == "tif":
+                        step = 1.0 / (synth.HGT_N - 1)
+                        f.write(synth.geotiff_bytes(nodes, float(cell[1]), float(cell[0] + 1), step, step))
+                    else:
+                        f.write(synth.hgt_bytes(nodes))
+                return cell, nodes
+            with concurrent.futures.ThreadPoolExecutor(max(1, min(8, host_cores()))) as pool:
+                self.nodes = dict(pool.map(make, self.cells))
+        node_barrier(env)
         self.stepper = TA.Stepper()
         if use_stack:
             self.handle = TA.Stack(self.tmp, stack_size)
             self.handle.load()      # up to stack_size tiles (0: all of them: no paging rounds)
             self.stepper.add_stack(self.handle, 0.0)
         else:
-            self.handle = TA.Map.load(os.path.join(self.tmp, synth.hgt_name(lat0, lon0)))
+            self.handle = TA.Map.load(os.path.join(self.tmp, name(lat0, lon0)))
             self.stepper.add_map(self.handle, 0.0)
         self.lat_range = (float(lat0), float(lat0 + nlat))
         self.lon_range = (float(lon0), float(lon0 + nlon))
+
+    def hgt_files(self):
+        """the same tiles as .hgt files, for the reference on the CPU: its GeoTIFF reader
+        dlopen()s "libtiff.so", a name this image has only with a version behind it"""
+        from turtle_amd import synth
+        if self.fmt == "hgt":
+            return self.tmp
+        if self.hgt_dir is None:
+            self.hgt_dir = self.tmp + "_as_hgt"
+            shutil.rmtree(self.hgt_dir, ignore_errors=True)
+            os.makedirs(self.hgt_dir)
+
+            def make(cell):
+                with open(os.path.join(self.hgt_dir, synth.hgt_name(*cell)), "wb") as f:
+                    f.write(synth.hgt_bytes(self.nodes[cell]))
+            with concurrent.futures.ThreadPoolExecutor(max(1, min(8, host_cores()))) as pool:
+                list(pool.map(make, self.cells))
+        return self.hgt_dir
 
     def oracle(self):
         """oracle/ geometry of the same terrain (the checker, never the product)"""
@@ -154,7 +193,11 @@ class Terrain:
     def close(self):
         self.stepper.destroy()
         self.handle.destroy()
-        shutil.rmtree(self.tmp, ignore_errors=True)
+        node_barrier(self.env)      # nobody reads the files any more
+        if self.env["rank"] == 0:
+            shutil.rmtree(self.tmp, ignore_errors=True)
+            if self.hgt_dir is not None:
+                shutil.rmtree(self.hgt_dir, ignore_errors=True)
 
 
 def parity_counts(index, length, ref_index, ref_length):
@@ -192,18 +235,27 @@ def cpu_baseline(terrain, pos, d, cores):
     one = geo.trace(pos[: max(1, n_rays // cores)], d[: max(1, n_rays // cores)],
                     local_range=0.0, threads=1)
     out["one_core"] = one["total_steps"] / (time.perf_counter() - t0)
-    if (not terrain.use_stack) and R.driver_available():
-        lat0, lon0 = terrain.tiles[:2]
-        path = os.path.join(terrain.tmp, synth.hgt_name(lat0, lon0))
-        R.trace_map(path, pos[:20000], d[:20000], local_range=1.0, threads=cores)   # warm up
+    if R.driver_available():
+        if terrain.use_stack:
+            # the reference's threaded pattern [ref examples/example-pthread.c:66-125]: one
+            # stack with lock / unlock shared by the threads, a client per worker
+            path = terrain.hgt_files()
+            run = lambda p, dd, rng, th: R.stack_run(path, p, dd, local_range=rng, threads=th)
+        else:
+            lat0, lon0 = terrain.tiles[:2]
+            path = os.path.join(terrain.tmp, synth.hgt_name(lat0, lon0))
+            run = lambda p, dd, rng, th: R.trace_map(path, p, dd, local_range=rng, threads=th)
+        run(pos[:20000], d[:20000], 1.0, cores)   # warm up
         for tag, rng in (("ref_range1", 1.0), ("ref_range0", 0.0)):
-            a = R.trace_map(path, pos, d, local_range=rng, threads=cores)
+            a = run(pos, d, rng, cores)
             out[tag] = a["total_steps"] / a["seconds"]
         out["ref_equal"] = bool(np.array_equal(a["index"], res["index"]) and
                                 np.array_equal(a["length"], res["length"]))
-        a = R.trace_map(path, pos[: max(1, n_rays // cores)], d[: max(1, n_rays // cores)],
-                        local_range=1.0, threads=1)
+        a = run(pos[: max(1, n_rays // cores)], d[: max(1, n_rays // cores)], 1.0, 1)
         out["ref_one_core"] = a["total_steps"] / a["seconds"]
+        out["ref_how"] = ("one turtle_stack with lock / unlock shared by the threads, a client per "
+                          "worker (the reference's threaded example)" if terrain.use_stack else
+                          "one stepper per thread over a shared map")
     return out, res
 
 
@@ -214,8 +266,9 @@ def cpu_baseline_entry(cpu, cores, n_rays):
     if "ref_range1" in cpu:
         return {"value": cpu["ref_range1"], "unit": "ray-steps/s", "cores": cores, "kind": "reference",
                 "sample": f"{n_rays} rays of the same recipe through the reference itself "
-                          f"(oracle/_ref, turtle_stepper_step in the example harness's loop, one "
-                          f"stepper per thread, {cores} pthreads, its default local range of 1 m); "
+                          f"(oracle/_ref, turtle_stepper_step in the example harness's loop, "
+                          f"{cpu.get('ref_how', 'one stepper per thread')}, {cores} pthreads, its "
+                          f"default local range of 1 m); "
                           f"with the exact transform (range 0, what the GPU computes): "
                           f"{cpu['ref_range0']:.4g} steps/s; one core: {cpu['ref_one_core']:.4g}; "
                           f"results equal to the restatement's bit for bit: {cpu['ref_equal']}. "
@@ -235,7 +288,8 @@ def run_workload(name, args, env, headline):
 
     world, rank, dev = env["world"], env["rank"], env["dev"]
     tiles, use_stack, default_rays, text = WORKLOADS[name]
-    terrain = Terrain(TA, tiles, use_stack, rank, args.stack_size if use_stack else 0)
+    terrain = Terrain(TA, tiles, use_stack, env, args.stack_size if use_stack else 0,
+                      fmt=("tif" if (name == "c5" and args.tiles == "auto") or args.tiles == "tif" else "hgt"))
     stepper = terrain.stepper
     n_block = args.rays or default_rays
     blocks = max(1, args.blocks)
@@ -419,11 +473,34 @@ def run_workload(name, args, env, headline):
                                               w["length"][:m].cpu().numpy(), ref_index, total)
                 out["parity"]["note"] = ("a walk: a ray whose medium differs once has diverged for "
                                          "good, and so has every later step of it")
+                port = (f"oracle/ C restatement, one thread (its single-step entry point is scalar): "
+                        f"{cpu_steps / dt:.4g} steps/s")
                 out["cpu_baseline"] = {
                     "value": cpu_steps / dt, "unit": "ray-steps/s", "cores": 1, "kind": "port",
-                    "sample": f"{m} rays x {args.scatter_steps} steps, oracle/ C restatement, one thread "
-                              f"(its single-step entry point is scalar), directions from the library's "
-                              f"Philox"}
+                    "sample": f"{m} rays x {args.scatter_steps} steps, {port}, directions from the "
+                              f"library's Philox"}
+                from oracle import ref_ffi as R
+                if R.driver_available():
+                    # the reference itself, its threaded pattern, all granted cores; directions
+                    # drawn on the GPU by the library's Philox, a chunk of rays at a time
+                    path = terrain.hgt_files()
+                    chunk, secs, ref_steps, equal = 25_000, 0.0, 0, True
+                    for lo_ in range(0, m, chunk):
+                        hi_ = min(m, lo_ + chunk)
+                        dirs = np.stack([TA.isotropic(hi_ - lo_, SEED, k, first_ray=first_ray + lo_,
+                                                      device=False) for k in range(args.scatter_steps)])
+                        a = R.stack_run(path, p_host[lo_:hi_], dirs, walk_steps=args.scatter_steps,
+                                        local_range=1.0, threads=cores)
+                        secs += a["seconds"]
+                        ref_steps += a["total_steps"]
+                    out["cpu_baseline"] = {
+                        "value": ref_steps / secs, "unit": "ray-steps/s", "cores": cores, "kind": "reference",
+                        "sample": f"{m} rays x {args.scatter_steps} steps through the reference itself "
+                                  f"(oracle/_ref; one turtle_stack with lock / unlock shared by {cores} "
+                                  f"pthreads, a client per worker: the reference's threaded example; its "
+                                  f"default local range of 1 m; the same tiles as .hgt files -- its GeoTIFF "
+                                  f"reader wants libtiff under a name this image lacks); {ref_steps} steps "
+                                  f"against the restatement's {cpu_steps}.  For comparison the {port}"}
             else:
                 cpu, res = cpu_baseline(terrain, p_host, d_host, cores)
                 out["parity"] = parity_counts(index[:m].cpu().numpy(), length[:m].cpu().numpy(),
@@ -459,7 +536,22 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=1_000_000,
                     help="rays of the headline's CPU-baseline sample (default: the whole C2 batch)")
     ap.add_argument("--no-cpu", action="store_true", help="no CPU baseline, no parity count")
+    ap.add_argument("--tiles", choices=("auto", "hgt", "tif"), default="auto",
+                    help="tile files: SRTM's .hgt, ASTER-GDEM2's GeoTIFF-16 (auto: tif for c5, hgt else)")
     args = ap.parse_args()
+
+    # `bench.py --gpus N` on its own: start the N ranks as a CHILD job (before anything here
+    # has touched a GPU: a process that has must never exec), relay rank 0's line and code
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
@@ -468,8 +560,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE {world}")
     # one process per GPU; TURTLE_BENCH_BACKEND=gloo lets several ranks share a
     # GPU to rehearse the N > 1 path on a one-GPU box (RCCL needs a GPU per rank)
     backend = os.environ.get("TURTLE_BENCH_BACKEND", "nccl")
@@ -499,16 +590,24 @@ def main():
     head = run_workload(head_name, args, env, headline=True)
     also = args.also
     if also is None:
-        also = "c3,c3@8,c4,c5" if (args.workload is None and world == 1) else "none"
+        also = "c3,c3@8,c4,c5,c2!strict,c3!strict" if (args.workload is None and world == 1) else "none"
     extra = {}
     for name in [w for w in also.split(",") if w and w != "none"]:
         sub = argparse.Namespace(**vars(args))
         sub.rays, sub.blocks, sub.sort, sub.sort_steps, sub.stack_size = 0, 1, 0, 0, 0
         if name.endswith("@8"):      # C3's second leg: the same workload, 8 of its 16 tiles resident
             name, sub.stack_size = name[:-2], 8
-        r = run_workload(name, sub, env, headline=False)
+        strict = name.endswith("!strict")   # the reference's arithmetic, operand for operand
+        if strict:
+            name, sub.no_cpu = name[:-7], True
+            TA.set_math("strict")
+        try:
+            r = run_workload(name, sub, env, headline=False)
+        finally:
+            if strict:
+                TA.set_math(os.environ.get("TURTLE_AMD_MATH", "fast"))
         if rank == 0:
-            extra[name + (f"_stack_size_{sub.stack_size}" if sub.stack_size else "")] = {"metric": "ray-steps/s", "value": r["value"], "passes": 1,
+            extra[name + (f"_stack_size_{sub.stack_size}" if sub.stack_size else "") + ("_strict" if strict else "")] = {"metric": "ray-steps/s", "value": r["value"], "passes": 1,
                            "ms_per_pass": r["ms_per_step"], "config": r["config"],
                            "kernel": r["kernel"], "roofline": r["roofline"],
                            **({"parity": r["parity"]} if "parity" in r else {}),

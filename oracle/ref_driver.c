@@ -8,8 +8,14 @@
  * examples/example-stepper.c:116-140] -- sample the start point, then
  * turtle_stepper_step until the medium changes -- over n rays, on `threads`
  * pthreads with one stepper each (a stepper is not re-entrant [ref
- * src/turtle/stepper.h:101-110]) sharing one read-only map.  Only the
- * reference's PUBLIC API is used; this file contains none of its code.
+ * src/turtle/stepper.h:101-110]) sharing one read-only map -- or, for the
+ * stack configurations (C3, C5), the pattern of the reference's threaded example
+ * [ref examples/example-pthread.c:66-125]: ONE turtle_stack shared by every
+ * thread, created with lock / unlock callbacks (a mutex here, a semaphore
+ * there), and one client per worker -- the one a stepper makes for itself when
+ * it is given a locked stack [ref src/turtle/stepper.c:411-470].  The walk of C5
+ * (a new direction at every step) takes its directions from the caller.  Only
+ * the reference's PUBLIC API is used; this file contains none of its code.
  */
 #define _POSIX_C_SOURCE 200809L
 #include "turtle.h" /* the reference's header: -I$(REF)/include, build container only */
@@ -20,6 +26,9 @@
 #include <time.h>
 
 struct job {
+        struct turtle_stack * stack; /* or NULL: the map */
+        int walk_steps;              /* > 0: a scattering walk of that many steps; direction[k][r][3] */
+        long n;
         struct turtle_map * map;
         double range, slope, resolution;
         long begin, end;
@@ -38,7 +47,9 @@ static void * worker(void * arg)
         struct job * job = arg;
         struct turtle_stepper * stepper = NULL;
         if ((turtle_stepper_create(&stepper) != TURTLE_RETURN_SUCCESS) ||
-            (turtle_stepper_add_map(stepper, job->map, 0.) != TURTLE_RETURN_SUCCESS)) {
+            (((job->stack != NULL) ? turtle_stepper_add_stack(stepper, job->stack, 0.) :
+                                     turtle_stepper_add_map(stepper, job->map, 0.)) !=
+                TURTLE_RETURN_SUCCESS)) {
                 job->failed = 1;
                 return NULL;
         }
@@ -54,7 +65,18 @@ static void * worker(void * arg)
                 int n = 0;
                 turtle_stepper_step(stepper, pos, NULL, NULL, NULL, NULL, NULL, NULL, idx);
                 const int medium = idx[0];
-                if (medium >= 0) {
+                if (job->walk_steps > 0) {
+                        /* C5: a new direction at every step; a ray that has left the
+                         * data takes no further step */
+                        int k;
+                        for (k = 0; (k < job->walk_steps) && (idx[0] >= 0); k++) {
+                                double ds;
+                                turtle_stepper_step(stepper, pos, job->direction + 3 * ((long)k * job->n + r),
+                                    NULL, NULL, NULL, NULL, &ds, idx);
+                                total += ds;
+                                n++;
+                        }
+                } else if (medium >= 0) {
                         while (n < job->max_steps) {
                                 double ds;
                                 turtle_stepper_step(
@@ -116,5 +138,60 @@ long ref_trace_map_n(const char * map_path, double range, double slope, double r
         free(jobs);
         free(tid);
         turtle_map_destroy(&map);
+        return steps;
+}
+
+static pthread_mutex_t stack_mutex = PTHREAD_MUTEX_INITIALIZER;
+static int stack_lock(void) { return pthread_mutex_lock(&stack_mutex); }
+static int stack_unlock(void) { return pthread_mutex_unlock(&stack_mutex); }
+
+/* The same through a turtle_stack over the tiles in `stack_path` (.hgt), shared by
+ * `threads` workers with a client each; walk_steps > 0: the scattering walk of C5,
+ * direction[walk_steps][n][3], else the trace to the first boundary, direction[n][3].
+ * The tiles are loaded before the clock starts (stack_size 0: all of them). */
+long ref_stack_n(const char * stack_path, int stack_size, double range, double slope,
+    double resolution, long n, double * position, const double * direction, int max_steps,
+    int walk_steps, int * index, double * length, int * n_steps, int threads, double * seconds)
+{
+        turtle_error_handler_set(NULL);
+        struct turtle_stack * stack = NULL;
+        if (turtle_stack_create(&stack, stack_path, stack_size, &stack_lock, &stack_unlock) !=
+            TURTLE_RETURN_SUCCESS)
+                return -1;
+        if (turtle_stack_load(stack) != TURTLE_RETURN_SUCCESS) {
+                turtle_stack_destroy(&stack);
+                return -1;
+        }
+        if (threads < 1) threads = 1;
+        struct job * jobs = calloc((size_t)threads, sizeof(*jobs));
+        pthread_t * tid = calloc((size_t)threads, sizeof(*tid));
+        long steps = -1;
+        if ((jobs != NULL) && (tid != NULL)) {
+                int t;
+                for (t = 0; t < threads; t++) {
+                        struct job * j = &jobs[t];
+                        j->stack = stack, j->walk_steps = walk_steps, j->n = n;
+                        j->range = range, j->slope = slope, j->resolution = resolution;
+                        j->begin = n * t / threads, j->end = n * (t + 1) / threads;
+                        j->position = position, j->direction = direction;
+                        j->max_steps = max_steps;
+                        j->index = index, j->length = length, j->n_steps = n_steps;
+                }
+                struct timespec t0, t1;
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                for (t = 0; t < threads; t++) pthread_create(&tid[t], NULL, worker, &jobs[t]);
+                for (t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if (seconds != NULL)
+                        *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+                steps = 0;
+                for (t = 0; t < threads; t++) {
+                        steps += jobs[t].steps;
+                        if (jobs[t].failed) steps = -1;
+                }
+        }
+        free(jobs);
+        free(tid);
+        turtle_stack_destroy(&stack);
         return steps;
 }

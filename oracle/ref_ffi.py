@@ -357,3 +357,30 @@ def trace_map(map_path, position, direction, local_range=1.0, slope=0.4, resolut
         raise RuntimeError(f"the reference could not load {map_path}")
     return dict(position=pos, index=index, length=length, n_steps=nsteps, total_steps=int(total),
                 seconds=seconds.value)
+
+
+def stack_run(stack_path, position, direction, walk_steps=0, stack_size=0, local_range=1.0, slope=0.4,
+              resolution=1e-2, max_steps=100000, threads=1):
+    """n rays through the turtle_stack over the .hgt tiles in `stack_path`, stepped by the REAL
+    reference: ONE stack with lock / unlock shared by `threads` pthreads, a client per worker (the
+    reference's threaded example).  walk_steps = 0: each ray to its first boundary, direction[n][3];
+    walk_steps > 0: a scattering walk of that many steps, direction[walk_steps][n][3]."""
+    L = C.CDLL(DRIVER_PATH)
+    L.ref_stack_n.restype = C.c_long
+    pos = np.array(position, dtype=np.float64, order="C").reshape(-1, 3)
+    n = pos.shape[0]
+    dire = np.ascontiguousarray(direction, dtype=np.float64)
+    assert dire.size == 3 * n * max(1, walk_steps)
+    index = np.empty((n, 2), dtype=np.int32)
+    length = np.empty(n, dtype=np.float64)
+    nsteps = np.empty(n, dtype=np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    seconds = C.c_double(0.0)   # the stepping alone: the tiles are loaded before the clock starts
+    total = L.ref_stack_n(os.fsencode(stack_path), C.c_int(stack_size), D(local_range), D(slope),
+                          D(resolution), C.c_long(n), vp(pos), vp(dire), C.c_int(max_steps),
+                          C.c_int(walk_steps), vp(index), vp(length), vp(nsteps), C.c_int(threads),
+                          C.byref(seconds))
+    if total < 0:
+        raise RuntimeError(f"the reference could not make a stack of {stack_path}")
+    return dict(position=pos, index=index, length=length, n_steps=nsteps, total_steps=int(total),
+                seconds=seconds.value)

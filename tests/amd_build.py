@@ -39,10 +39,11 @@ def hgt_tile(tmpdir, lat0=45, lon0=3, n=synth.HGT_N):
     return TA.Map.load(synth.write_hgt(str(tmpdir), lat0, lon0, n))
 
 
-def mosaic(tmpdir, tiles, n):
+def mosaic(tmpdir, tiles, n, fmt="hgt"):
+    """a stack over synthetic 1x1 degree tiles: SRTM's .hgt, or ASTER-GDEM2's GeoTIFF"""
     d = os.path.join(str(tmpdir), "mosaic")
     for la, lo in tiles:
-        synth.write_hgt(d, la, lo, n)
+        (synth.write_geotiff if fmt == "tif" else synth.write_hgt)(d, la, lo, n)
     with open(os.path.join(d, "README.txt"), "w") as f:
         f.write("not a map\n")
     return TA.Stack(d, 0)

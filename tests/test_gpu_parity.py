@@ -199,6 +199,26 @@ def test_hgt_tile_traces(golden, tmp_path, math):
     m.destroy()
 
 
+def test_outputs_not_asked_for_change_nothing(math):
+    """A caller that wants no path lengths or step counts gets the same media and end points, to
+    the bit, from the same kernels (the trace's own counters say so) as one that wants them."""
+    m = TA.Map.create(T.c1_nodes(), T.C1_X, T.C1_Y, T.C1_Z)
+    st = B.c1_stepper(m)
+    lat, lon, az, el = synth.uniform_rays(20000, T.C1_Y, T.C1_X, seed=77)
+    pos, _ = st.position(lat, lon, 500.0)
+    d = TA.ecef_from_horizontal(lat, lon, az, el)
+    full = st.trace(pos.copy(), d)
+    stats = st.trace_stats()
+    for want in ((), ("length",), ("n_steps",)):
+        t = st.trace(pos.copy(), d, want=want)
+        assert t["length"] is None or np.array_equal(t["length"], full["length"])
+        assert t["n_steps"] is None or np.array_equal(t["n_steps"], full["n_steps"])
+        assert np.array_equal(t["index"], full["index"]) and np.array_equal(t["position"], full["position"])
+        assert st.trace_stats() == stats, (want, st.trace_stats(), stats)
+    st.destroy()
+    m.destroy()
+
+
 def test_c3_seams_of_full_size_tiles(golden, tmp_path, math):
     """C3's shape at full tile size: a stack of 3601^2 tiles, rays that start
     within 0.01 degree of a seam and cross it, run along it or leave through the rim --
@@ -878,16 +898,36 @@ def test_two_ranks_share_the_gpu_through_bench(tmp_path):
     assert lines[0]["tally"] == lines[1]["tally"]
     assert sum(lines[0]["tally"]["hits"]) == 300000
     assert lines[0]["kernel"]["steps_per_launch"] * 2 > lines[1]["kernel"]["steps_per_launch"] > 0
+    # and `python bench.py --gpus 2` by itself, as the driver calls it: it starts its two
+    # ranks as a child job and relays rank 0's line and the exit code
+    own = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=root,
+                         env={k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    rows = [l for l in own.stdout.splitlines() if l.startswith("{")]
+    assert own.returncode == 0 and len(rows) == 1, (own.stdout[-500:], own.stderr[-1500:])
+    assert json.loads(rows[0])["n_gpus"] == 2 and json.loads(rows[0])["tally"] == lines[0]["tally"]
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "nope"],
+                         capture_output=True, text=True, timeout=120, cwd=root)
+    assert bad.returncode != 0
 
 
-def test_scatter_over_a_stack_against_the_oracle(math, tmp_path):
+@pytest.mark.parametrize("fmt", ["hgt", "tif"])
+def test_scatter_over_a_stack_against_the_oracle(math, tmp_path, fmt):
     """Config C5 in small, on its real kind of terrain: a walk of 64 generations over a
     3 x 3 mosaic with a hole (seams, the rim, rays that leave), every step against the
-    CPU restatement's single steps, directions from the library's Philox."""
+    CPU restatement's single steps, directions from the library's Philox.  The tiles as
+    SRTM ships them (.hgt) and as ASTER-GDEM2 does, the terrain BASELINE names for C5:
+    GeoTIFF, int16 (the reference reads those files as it reads the .hgt ones:
+    tests/golden/check_geotiff_tiles_with_reference.py)."""
     tiles = [(la, lo) for la in (45, 46, 47) for lo in (3, 4, 5) if (la, lo) != (46, 4)]
-    stack = B.mosaic(tmp_path, tiles, 1201)
+    stack = B.mosaic(tmp_path, tiles, 1201, fmt)
     stack.load()
     geo = T.mosaic_oracle(tiles, 1201, 45, 3, 3, 3)
+    rng = np.random.default_rng(9)
+    qlat, qlon = rng.uniform(44.9, 48.1, 4096), rng.uniform(2.9, 6.1, 4096)
+    z, inside = stack.elevation(qlat, qlon)
+    zo, io = geo.stack_elevation(0, qlat, qlon)
+    assert np.array_equal(inside, io) and np.array_equal(z, zo)   # tile selection and bilinear: bit-exact
     st = TA.Stepper()
     st.add_stack(stack, 0.0)
     n, K = 6000, 64

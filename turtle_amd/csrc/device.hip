@@ -2347,7 +2347,11 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                         } else
                                 d_sample<MODE, FAST>(v, ctx, qx, qy, qz, s,
                                     (FAST && (MODE != TAMD_MODE_GENERIC)) ? &cell : nullptr);
-                        my_samples += defer ? 0 : 1;
+                        /* (a ray that phase A handed over before its line starts -- when
+                         * its queue ran dry: which rays, depends on the scheduling -- samples
+                         * its position again here: not one of the trace's samples, so that
+                         * the count is the same from run to run) */
+                        my_samples += (defer || (MODEL && !lined_ && (state == ST_INIT))) ? 0 : 1;
                         if (CAN_FAULT && !defer && (s.fault.centre >= 0)) {
                                 /* a tile that is not resident: the ray goes back to
                                  * the arrays as it was BEFORE this sample (before the

@@ -72,3 +72,44 @@ def uniform_rays(n: int, lat_range, lon_range, seed: int = 0x5EED2026,
     az = 360.0 * u[2]
     el = el_range[0] + (el_range[1] - el_range[0]) * u[3]
     return lat, lon, az, el
+
+
+def geotiff_name(lat0: int, lon0: int) -> str:
+    """ASTER-GDEM2's tile name (the terrain BASELINE's C5 names)"""
+    ns = "N" if lat0 >= 0 else "S"
+    ew = "E" if lon0 >= 0 else "W"
+    return f"ASTGTM2_{ns}{abs(lat0):02d}{ew}{abs(lon0):03d}_dem.tif"
+
+
+def geotiff_bytes(nodes_s2n: np.ndarray, lon0: float, lat1: float, dx: float, dy: float) -> bytes:
+    """The grid as an uncompressed single-strip GeoTIFF of int16 samples, little-endian, scan
+    lines north->south, with the two GeoTIFF tags the reference reads: ModelPixelScale (33550)
+    and ModelTiepoint (33922) [ref src/turtle/io/geotiff16.c:205-214]."""
+    import struct
+    ny, nx = nodes_s2n.shape
+    data = np.ascontiguousarray(nodes_s2n[::-1, :]).astype("<i2").tobytes()
+    scale = struct.pack("<3d", dx, dy, 0.0)
+    tie = struct.pack("<6d", 0.0, 0.0, 0.0, lon0, lat1, 0.0)
+    n_tags = 12
+    ifd_at = 8
+    extra_at = ifd_at + 2 + 12 * n_tags + 4
+    scale_at, tie_at = extra_at, extra_at + len(scale)
+    data_at = tie_at + len(tie)
+    def tag(code, kind, count, value):
+        return struct.pack("<HHII", code, kind, count, value)
+    tags = [tag(256, 4, 1, nx), tag(257, 4, 1, ny), tag(258, 3, 1, 16), tag(259, 3, 1, 1),
+            tag(262, 3, 1, 1), tag(273, 4, 1, data_at), tag(277, 3, 1, 1), tag(278, 4, 1, ny),
+            tag(279, 4, 1, len(data)), tag(339, 3, 1, 2), tag(33550, 12, 3, scale_at),
+            tag(33922, 12, 6, tie_at)]
+    return (b"II" + struct.pack("<HI", 42, ifd_at) + struct.pack("<H", n_tags) + b"".join(tags) +
+            struct.pack("<I", 0) + scale + tie + data)
+
+
+def write_geotiff(directory: str, lat0: int, lon0: int, n: int = HGT_N) -> str:
+    """One 1x1 degree tile of the synthetic terrain as ASTER-GDEM2 ships it: GeoTIFF, int16"""
+    os.makedirs(directory, exist_ok=True)
+    path = os.path.join(directory, geotiff_name(lat0, lon0))
+    step = 1.0 / (n - 1)
+    with open(path, "wb") as f:
+        f.write(geotiff_bytes(srtm_like_nodes(lat0, lon0, n), float(lon0), float(lat0 + 1), step, step))
+    return path
