@@ -3107,6 +3107,21 @@ extern "C" int tamd_dev_pinned(void ** ptr, size_t bytes)
         return 0;
 }
 
+/* page-locked host memory that outlives the call (a stack's staging buffers for its
+ * tiles: a copy from it is queued, not waited for) */
+extern "C" int tamd_dev_host_alloc(void ** ptr, size_t bytes)
+{
+        *ptr = nullptr;
+        if (tamd_dev_init()) return 1;
+        HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+        return 0;
+}
+
+extern "C" void tamd_dev_host_free(void * ptr)
+{
+        if (ptr != nullptr) (void)hipHostFree(ptr);
+}
+
 extern "C" int tamd_dev_copy_async(void * dst, const void * src, size_t bytes, int to_device)
 {
         if (tamd_dev_init()) return 1;

@@ -55,30 +55,33 @@ int tamd_hgt_probe(const char * path, struct turtle_map * m)
         return TURTLE_RETURN_SUCCESS;
 }
 
-int tamd_hgt_read(const char * path, struct turtle_map * m)
+/* grid rows iy0 .. iy1 - 1 (file row r is grid row ny - 1 - r): the rows of a tile
+ * are read band by band, a worker thread each (tiles.c) */
+int tamd_hgt_read_rows(const char * path, struct turtle_map * m, int iy0, int iy1)
 {
         FILE * fid = fopen(path, "rb");
         if (fid == NULL) return TURTLE_RETURN_PATH_ERROR;
         const size_t nx = m->nx, ny = m->ny;
-        uint16_t * row = malloc(nx * sizeof(*row));
-        if (row == NULL) {
-                fclose(fid);
-                return TURTLE_RETURN_MEMORY_ERROR;
-        }
         int rc = TURTLE_RETURN_SUCCESS;
+        if (fseek(fid, (long)((ny - (size_t)iy1) * nx * sizeof(uint16_t)), SEEK_SET) != 0)
+                rc = TURTLE_RETURN_BAD_FORMAT + 100;
         size_t r, i;
-        for (r = 0; r < ny; r++) { /* file row r is grid row ny-1-r */
-                if (fread(row, sizeof(*row), nx, fid) != nx) {
+        for (r = ny - (size_t)iy1; (r < ny - (size_t)iy0) && (rc == TURTLE_RETURN_SUCCESS); r++) {
+                uint16_t * dst = m->nodes + (ny - 1 - r) * nx;
+                if (fread(dst, sizeof(*dst), nx, fid) != nx) {
                         rc = TURTLE_RETURN_BAD_FORMAT + 100; /* "missing data" */
                         break;
                 }
-                uint16_t * dst = m->nodes + (ny - 1 - r) * nx;
-                for (i = 0; i < nx; i++) {
-                        const unsigned char * b = (const unsigned char *)&row[i];
+                for (i = 0; i < nx; i++) { /* big-endian on file [ref io/hgt.c:127-131] */
+                        const unsigned char * b = (const unsigned char *)&dst[i];
                         dst[i] = (uint16_t)((b[0] << 8) | b[1]);
                 }
         }
-        free(row);
         fclose(fid);
         return rc;
+}
+
+int tamd_hgt_read(const char * path, struct turtle_map * m)
+{
+        return tamd_hgt_read_rows(path, m, 0, m->ny);
 }

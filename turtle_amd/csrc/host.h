@@ -53,6 +53,10 @@ struct turtle_map {
         uint16_t * nodes;     /* host copy: native endian, rows south->north */
         void * d_nodes[TAMD_MAX_DEVICES]; /* HBM copies (in blocks: internal.h), one per device */
         unsigned d_fresh;     /* bit d: the copy on device d is current */
+        /* a tile of a stack, just read: its nodes in the HBM layout, in one of the stack's
+         * page-locked staging buffers (slot `staged_slot`), waiting for their first upload */
+        uint16_t * staged;
+        int staged_slot;
 };
 
 /* What threads share -- the HBM copies of a map, the tiles of a stack, the epoch
@@ -86,8 +90,10 @@ enum turtle_return tamd_map_load_(struct turtle_map ** map, const char * path,
  * "inconsistent data", + 102 for "could not read the header". */
 int tamd_hgt_probe(const char * path, struct turtle_map * meta);
 int tamd_hgt_read(const char * path, struct turtle_map * map);
+int tamd_hgt_read_rows(const char * path, struct turtle_map * map, int iy0, int iy1);
 int tamd_tiff_probe(const char * path, struct turtle_map * meta);
 int tamd_tiff_read(const char * path, struct turtle_map * map);
+int tamd_tiff_read_rows(const char * path, struct turtle_map * map, int iy0, int iy1);
 int tamd_png_probe(const char * path, struct turtle_map * meta);
 int tamd_png_read(const char * path, struct turtle_map * map);
 int tamd_grd_probe(const char * path, struct turtle_map * meta);
@@ -109,9 +115,44 @@ struct turtle_stack {
         char ** path;             /* [lat_n * long_n] file of each slot or NULL */
         struct turtle_map ** tile; /* [lat_n * long_n] loaded tile or NULL */
         unsigned long * stamp;    /* [lat_n * long_n] when the tile was last wanted */
+        const void ** owner;      /* [lat_n * long_n] the thread that has just paged the tile in and
+                                   * has not run its round over it yet (or NULL): nobody else's
+                                   * page-in or trim takes it away meanwhile, as the reference's
+                                   * clients pin the tile they use [ref stack.c:433-442] */
         unsigned long clock;
         int n_loaded, n_files;
+        /* Tiles come in through page-locked staging buffers (tiles.c): worker threads read and
+         * decode the files of a round side by side, straight into the HBM layout; the upload is
+         * a queued copy.  A slot is free again once the device it was copied to has drained
+         * (`stage_device`: -1 free, -2 holds a tile not uploaded yet). */
+#define TAMD_STAGE_SLOTS 16
+        uint16_t * stage[TAMD_STAGE_SLOTS];
+        int stage_device[TAMD_STAGE_SLOTS];
+        size_t stage_bytes;
+        /* HBM buffers of tiles that went, kept for the tiles that come (one size: the tiles of
+         * a stack have one shape): hipMalloc / hipFree wait for the device */
+#define TAMD_SPARE_HBM 16
+        void * spare[TAMD_MAX_DEVICES][TAMD_SPARE_HBM];
+        int n_spare[TAMD_MAX_DEVICES];
+        size_t spare_bytes;
 };
+
+/* tiles.c: the files of `n` tiles read and decoded by up to `threads` workers */
+struct tamd_tile_job {
+        const char * path;
+        uint16_t * staged;        /* in: a staging buffer of `staged_bytes`, or NULL */
+        size_t staged_bytes;
+        struct turtle_map * map;  /* out: the tile (calloc'ed; nodes malloc'ed), or NULL */
+        int rc;                   /* out: an enum turtle_return */
+};
+void tamd_tiles_decode(struct tamd_tile_job * jobs, int n);
+/* stack.c: a spare HBM buffer of that size on that device (or NULL); a tile's staging buffer
+ * has been copied from on `device` (-1: it was not, and is free) */
+void * tamd_stack_spare_take(struct turtle_stack * stack, int device, size_t bytes);
+void tamd_stack_staged_done(struct turtle_map * tile, int device);
+size_t tamd_blocked_bytes(int nx, int ny);
+void tamd_blocked_fill(const struct turtle_map * map, uint16_t * blocked);
+void tamd_blocked_fill_rows(const struct turtle_map * map, uint16_t * blocked, int iy0, int iy1);
 
 /* Tiles the stack keeps in memory between calls [ref stack.c:150]: max_size, or
  * no limit; tamd_stack_trim brings it back there when a batch call ends (while

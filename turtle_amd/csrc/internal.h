@@ -150,6 +150,9 @@ int tamd_dev_zero(void * dst, size_t bytes);                   /* stream-ordered
  * HBM that are queued on the thread's stream and not waited for */
 int tamd_dev_pinned(void ** ptr, size_t bytes);
 int tamd_dev_copy_async(void * dst, const void * src, size_t bytes, int to_device);
+/* page-locked host memory that outlives the call (tile staging) */
+int tamd_dev_host_alloc(void ** ptr, size_t bytes);
+void tamd_dev_host_free(void * ptr);
 
 /* Grow-only scratch arena for HOST-space calls: reset at the start of each
  * API call, handed out in 256-byte aligned pieces. */

@@ -308,31 +308,39 @@ int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
         const size_t bytes = nbx * nby * TAMD_BLOCK * TAMD_BLOCK * sizeof(*map->nodes);
         tamd_geometry_lock();
         if (map->d_nodes[device] == NULL) {
-                if (tamd_dev_malloc(&map->d_nodes[device], bytes)) {
+                /* a tile: the buffer of one that went, if its stack kept any */
+                map->d_nodes[device] = tamd_stack_spare_take(map->stack, device, bytes);
+                if ((map->d_nodes[device] == NULL) && tamd_dev_malloc(&map->d_nodes[device], bytes)) {
                         tamd_geometry_unlock();
                         return 1;
                 }
                 map->d_fresh &= ~(1u << device);
         }
         if (!(map->d_fresh & (1u << device))) {
-                uint16_t * blocked = calloc(1, bytes);
-                if (blocked == NULL) {
-                        tamd_geometry_unlock();
-                        return 1;
+                int failed;
+                if (map->staged != NULL) {
+                        /* a tile just read: laid out already, in page-locked memory
+                         * (tiles.c) */
+                        /* ... and waited for: the copy is on THIS thread's stream, and once
+                         * the tile reads "current" another thread's launches, on another
+                         * stream, may read it (26 MB from page-locked memory: half a
+                         * millisecond) */
+                        failed = tamd_dev_copy_async(map->d_nodes[device], map->staged, bytes, 1) ||
+                            tamd_dev_sync();
+                        tamd_stack_staged_done(map, -1);
+                } else {
+                        uint16_t * blocked = malloc(bytes);
+                        if (blocked == NULL) {
+                                tamd_geometry_unlock();
+                                return 1;
+                        }
+                        tamd_blocked_fill(map, blocked);
+                        /* (a copy being rewritten while launches of other threads read it:
+                         * turtle_map_fill on a map in use is the caller's race, as in the
+                         * reference) */
+                        failed = tamd_dev_h2d(map->d_nodes[device], blocked, bytes);
+                        free(blocked);
                 }
-                int ix, iy;
-                for (iy = 0; iy < map->ny; iy++) {
-                        const uint16_t * row = map->nodes + (size_t)iy * map->nx;
-                        uint16_t * to = blocked + ((size_t)(iy / TAMD_BLOCK) * nbx) * (TAMD_BLOCK * TAMD_BLOCK) +
-                            (size_t)(iy % TAMD_BLOCK) * TAMD_BLOCK;
-                        for (ix = 0; ix < map->nx; ix++)
-                                to[(size_t)(ix / TAMD_BLOCK) * (TAMD_BLOCK * TAMD_BLOCK) + ix % TAMD_BLOCK] = row[ix];
-                }
-                /* (a copy being rewritten while launches of other threads read it:
-                 * turtle_map_fill on a map in use is the caller's race, as in the
-                 * reference) */
-                const int failed = tamd_dev_h2d(map->d_nodes[device], blocked, bytes);
-                free(blocked);
                 if (failed) {
                         tamd_geometry_unlock();
                         return 1;

@@ -35,13 +35,6 @@ static int tile_probe(const char * path, struct turtle_map * meta)
         return probe(path, meta);
 }
 
-static int tile_read(const char * path, struct turtle_map * map)
-{
-        int (*probe)(const char *, struct turtle_map *);
-        int (*read)(const char *, struct turtle_map *);
-        if (!tamd_codec_for(path, &probe, &read)) return TURTLE_RETURN_BAD_EXTENSION;
-        return read(path, map);
-}
 
 /* [ref stack.c:46-213] */
 enum turtle_return turtle_stack_create(struct turtle_stack ** stack,
@@ -121,12 +114,15 @@ enum turtle_return turtle_stack_create(struct turtle_stack ** stack,
                 s->path = calloc(slots ? slots : 1, sizeof(*s->path));
                 s->tile = calloc(slots ? slots : 1, sizeof(*s->tile));
                 s->stamp = calloc(slots ? slots : 1, sizeof(*s->stamp));
+                s->owner = calloc(slots ? slots : 1, sizeof(*s->owner));
+                int k;
+                for (k = 0; k < TAMD_STAGE_SLOTS; k++) s->stage_device[k] = -1; /* free */
         }
         if ((s == NULL) || (s->root == NULL) || (s->path == NULL) || (s->tile == NULL) ||
-            (s->stamp == NULL)) {
+            (s->stamp == NULL) || (s->owner == NULL)) {
                 closedir(dir);
                 if (s != NULL) {
-                        free(s->root), free(s->path), free(s->tile), free(s->stamp);
+                        free(s->root), free(s->path), free(s->tile), free(s->stamp), free(s->owner);
                         free(s);
                 }
                 return TAMD_RAISE(TURTLE_RETURN_MEMORY_ERROR, "could not allocate memory");
@@ -158,6 +154,90 @@ enum turtle_return turtle_stack_create(struct turtle_stack ** stack,
         return TURTLE_RETURN_SUCCESS;
 }
 
+/* ---- staging buffers and spare HBM buffers (host.h) ------------------------ */
+
+/* a free staging buffer of at least `bytes`: its slot, or -1 (the tile then takes
+ * the slow way: laid out and copied when it is first needed) */
+static int stage_acquire(struct turtle_stack * s, size_t bytes)
+{
+        int k, slot = -1;
+        if ((s->stage_bytes != 0) && (bytes > s->stage_bytes)) return -1; /* (one shape a stack) */
+        for (k = 0; (k < TAMD_STAGE_SLOTS) && (slot < 0); k++)
+                if (s->stage_device[k] == -1) slot = k;
+        for (k = 0; (k < TAMD_STAGE_SLOTS) && (slot < 0); k++) {
+                if (s->stage_device[k] < 0) continue;
+                /* copied from, on that device: free once it has drained */
+                if (tamd_dev_sync_device(s->stage_device[k])) return -1;
+                int j;
+                const int device = s->stage_device[k];
+                for (j = 0; j < TAMD_STAGE_SLOTS; j++)
+                        if (s->stage_device[j] == device) s->stage_device[j] = -1;
+                slot = k;
+        }
+        if (slot < 0) return -1;
+        if (s->stage[slot] == NULL) {
+                void * p = NULL;
+                if (tamd_dev_host_alloc(&p, bytes)) return -1;
+                s->stage[slot] = p;
+                s->stage_bytes = bytes;
+        }
+        s->stage_device[slot] = -2;
+        return slot;
+}
+
+static void stage_release_all(struct turtle_stack * s)
+{
+        int k;
+        for (k = 0; k < TAMD_STAGE_SLOTS; k++) {
+                if (s->stage_device[k] >= 0) (void)tamd_dev_sync_device(s->stage_device[k]);
+                tamd_dev_host_free(s->stage[k]);
+                s->stage[k] = NULL, s->stage_device[k] = -1;
+        }
+        s->stage_bytes = 0;
+}
+
+/* the HBM buffers of a tile that goes are kept for the next to come (its device has
+ * drained: the caller holds the geometry for writing and has waited) */
+static void spare_keep(struct turtle_stack * s, struct turtle_map * m)
+{
+        int d;
+        const size_t bytes = tamd_blocked_bytes(m->nx, m->ny);
+        if (s->spare_bytes == 0) s->spare_bytes = bytes;
+        for (d = 0; d < TAMD_MAX_DEVICES; d++) {
+                if ((m->d_nodes[d] == NULL) || (bytes != s->spare_bytes) ||
+                    (s->n_spare[d] >= TAMD_SPARE_HBM))
+                        continue;
+                if (tamd_dev_sync_device(d)) continue; /* (it is freed the usual way) */
+                s->spare[d][s->n_spare[d]++] = m->d_nodes[d];
+                m->d_nodes[d] = NULL;
+                m->d_fresh &= ~(1u << d);
+        }
+}
+
+void * tamd_stack_spare_take(struct turtle_stack * s, int device, size_t bytes)
+{
+        if ((s == NULL) || (bytes != s->spare_bytes) || (s->n_spare[device] == 0)) return NULL;
+        return s->spare[device][--s->n_spare[device]];
+}
+
+static void spare_release_all(struct turtle_stack * s)
+{
+        int d, k;
+        for (d = 0; d < TAMD_MAX_DEVICES; d++) {
+                for (k = 0; k < s->n_spare[d]; k++) tamd_dev_free_on(d, s->spare[d][k]);
+                s->n_spare[d] = 0;
+        }
+        s->spare_bytes = 0;
+}
+
+/* a tile's staging buffer has been copied from (tamd_map_sync), or the tile goes */
+void tamd_stack_staged_done(struct turtle_map * m, int device)
+{
+        if ((m->stack != NULL) && (m->staged_slot >= 0) && (m->staged_slot < TAMD_STAGE_SLOTS))
+                m->stack->stage_device[m->staged_slot] = (device >= 0) ? device : -1;
+        m->staged = NULL, m->staged_slot = -1;
+}
+
 static void stack_release_tiles(struct turtle_stack * s)
 {
         const int n = s->latitude_n * s->longitude_n;
@@ -166,11 +246,14 @@ static void stack_release_tiles(struct turtle_stack * s)
         for (i = 0; i < n; i++) {
                 if (s->tile[i] == NULL) continue;
                 struct turtle_map * m = s->tile[i];
+                tamd_stack_staged_done(m, -1);
                 m->stack = NULL; /* do not walk back into the table */
                 turtle_map_destroy(&m);
-                s->tile[i] = NULL;
+                s->tile[i] = NULL, s->owner[i] = NULL;
         }
         s->n_loaded = 0;
+        stage_release_all(s);
+        spare_release_all(s);
         tamd_geometry_changed();
         tamd_geometry_write_end();
 }
@@ -184,7 +267,7 @@ void turtle_stack_destroy(struct turtle_stack ** stack)
         const int n = s->latitude_n * s->longitude_n;
         int i;
         for (i = 0; i < n; i++) free(s->path[i]);
-        free(s->path), free(s->tile), free(s->stamp), free(s->root);
+        free(s->path), free(s->tile), free(s->stamp), free(s->owner), free(s->root);
         free(s);
         *stack = NULL;
 }
@@ -213,21 +296,29 @@ int tamd_stack_budget(const struct turtle_stack * s)
         return (s->max_size <= 0) ? INT_MAX : s->max_size;
 }
 
-/* the least recently wanted tiles go until the stack is within its size */
+/* what names the calling thread in `owner` */
+static __thread char t_me;
+
+/* the least recently wanted tiles go until the stack is within its size (the call of
+ * this thread is over: what it had paged in for its next round is anybody's) */
 void tamd_stack_trim(struct turtle_stack * s)
 {
         const int n = s->latitude_n * s->longitude_n, budget = tamd_stack_budget(s);
-        if (s->n_loaded <= budget) return;
+        int i;
         if (s->lock != NULL) (void)s->lock();
         tamd_geometry_write_begin();
+        for (i = 0; i < n; i++)
+                if (s->owner[i] == &t_me) s->owner[i] = NULL;
         while (s->n_loaded > budget) {
-                int i, out = -1;
+                int out = -1;
                 for (i = 0; i < n; i++) {
-                        if (s->tile[i] == NULL) continue;
+                        if ((s->tile[i] == NULL) || (s->owner[i] != NULL)) continue;
                         if ((out < 0) || (s->stamp[i] < s->stamp[out])) out = i;
                 }
                 if (out < 0) break;
                 struct turtle_map * m = s->tile[out];
+                tamd_stack_staged_done(m, -1);
+                spare_keep(s, m);
                 m->stack = NULL; /* do not walk back into the table */
                 turtle_map_destroy(&m);
                 s->tile[out] = NULL;
@@ -249,33 +340,66 @@ int tamd_stack_is_paged(const struct turtle_stack * s)
         return (s->n_loaded < s->n_files) || (tamd_stack_budget(s) < s->n_files);
 }
 
-/* one tile from its file into memory (it goes on to HBM at the next device call) */
-static int stack_load_tile(struct turtle_stack * s, int i, char * message, size_t size)
+/* `count` tiles from their files into memory, side by side (tiles.c), each laid out
+ * in a staging buffer where one is free; they go on to HBM at the next device call.
+ * All of them or none: an enum turtle_return. */
+static int stack_load_tiles(struct turtle_stack * s, const int * which, int count, char * message,
+    size_t size)
 {
-        struct turtle_map * m = calloc(1, sizeof(*m));
-        int rc = (m == NULL) ? TURTLE_RETURN_MEMORY_ERROR : tile_probe(s->path[i], m);
-        if (rc == TURTLE_RETURN_SUCCESS) {
-                m->nodes = malloc((size_t)m->nx * m->ny * sizeof(*m->nodes));
-                rc = (m->nodes == NULL) ? TURTLE_RETURN_MEMORY_ERROR : tile_read(s->path[i], m);
+        if (count <= 0) return TURTLE_RETURN_SUCCESS;
+        struct tamd_tile_job * jobs = calloc((size_t)count, sizeof(*jobs));
+        int * slot = malloc((size_t)count * sizeof(*slot));
+        if ((jobs == NULL) || (slot == NULL)) {
+                free(jobs), free(slot);
+                snprintf(message, size, "could not allocate memory");
+                return TURTLE_RETURN_MEMORY_ERROR;
         }
-        if (rc != TURTLE_RETURN_SUCCESS) {
-                if (m != NULL) free(m->nodes);
-                free(m);
-                if (rc > N_TURTLE_RETURNS) rc = TURTLE_RETURN_BAD_FORMAT;
-                snprintf(message, size, "could not load tile `%s'", s->path[i]);
-                return rc;
+        int k, rc = TURTLE_RETURN_SUCCESS;
+        struct turtle_map meta;
+        size_t bytes = s->stage_bytes;
+        if ((bytes == 0) && (tile_probe(s->path[which[0]], &meta) == TURTLE_RETURN_SUCCESS))
+                bytes = tamd_blocked_bytes(meta.nx, meta.ny);
+        for (k = 0; k < count; k++) {
+                jobs[k].path = s->path[which[k]];
+                slot[k] = (bytes > 0) ? stage_acquire(s, bytes) : -1;
+                jobs[k].staged = (slot[k] >= 0) ? s->stage[slot[k]] : NULL;
+                jobs[k].staged_bytes = s->stage_bytes;
         }
-        m->stack = s;
-        s->tile[i] = m;
-        s->stamp[i] = ++s->clock;
-        s->n_loaded++;
-        tamd_geometry_changed();
-        return TURTLE_RETURN_SUCCESS;
+        tamd_tiles_decode(jobs, count);
+        for (k = 0; k < count; k++) {
+                if ((jobs[k].rc != TURTLE_RETURN_SUCCESS) && (rc == TURTLE_RETURN_SUCCESS)) {
+                        rc = jobs[k].rc;
+                        snprintf(message, size, "could not load tile `%s'", jobs[k].path);
+                }
+        }
+        for (k = 0; k < count; k++) {
+                struct turtle_map * m = jobs[k].map;
+                if ((rc != TURTLE_RETURN_SUCCESS) || (m == NULL) || (m->staged == NULL)) {
+                        if (slot[k] >= 0) s->stage_device[slot[k]] = -1;
+                        if (m != NULL) m->staged = NULL, m->staged_slot = -1;
+                } else
+                        m->staged_slot = slot[k];
+                if (m == NULL) continue;
+                if (rc != TURTLE_RETURN_SUCCESS) {
+                        free(m->nodes), free(m);
+                        continue;
+                }
+                m->stack = s;
+                s->tile[which[k]] = m;
+                s->stamp[which[k]] = ++s->clock;
+                s->n_loaded++;
+        }
+        if (rc == TURTLE_RETURN_SUCCESS) tamd_geometry_changed();
+        free(jobs), free(slot);
+        return rc;
 }
 
 static void stack_drop_tile(struct turtle_stack * s, int i)
 {
         struct turtle_map * m = s->tile[i];
+        s->owner[i] = NULL;
+        tamd_stack_staged_done(m, -1);
+        spare_keep(s, m);
         m->stack = NULL; /* do not walk back into the table */
         turtle_map_destroy(&m);
         s->tile[i] = NULL;
@@ -286,13 +410,18 @@ static void stack_drop_tile(struct turtle_stack * s, int i)
 int tamd_stack_preload(struct turtle_stack * s, char * message, size_t size)
 {
         const int n = s->latitude_n * s->longitude_n, budget = tamd_stack_budget(s);
-        int i, rc = TURTLE_RETURN_SUCCESS;
+        int i, rc = TURTLE_RETURN_SUCCESS, count = 0;
+        int * which = malloc((size_t)(n ? n : 1) * sizeof(*which));
+        if (which == NULL) return TURTLE_RETURN_MEMORY_ERROR;
         tamd_geometry_lock();
-        for (i = 0; (i < n) && (s->n_loaded < budget) && (rc == TURTLE_RETURN_SUCCESS); i++) {
-                if ((s->path[i] == NULL) || (s->tile[i] != NULL)) continue;
-                rc = stack_load_tile(s, i, message, size);
-        }
+        for (i = 0; (i < n) && (s->n_loaded + count < budget); i++)
+                if ((s->path[i] != NULL) && (s->tile[i] == NULL)) which[count++] = i;
+        /* (a batch of tiles at a time: each holds a staging buffer until it is uploaded) */
+        for (i = 0; (i < count) && (rc == TURTLE_RETURN_SUCCESS); i += TAMD_STAGE_SLOTS)
+                rc = stack_load_tiles(s, which + i, (count - i < TAMD_STAGE_SLOTS) ? count - i : TAMD_STAGE_SLOTS,
+                    message, size);
         tamd_geometry_unlock();
+        free(which);
         return rc;
 }
 
@@ -325,15 +454,30 @@ static int stack_page_in(struct turtle_stack * s, const unsigned * wanted,
         int i, loaded = 0;
 #define FIRST(i) ((wanted_first[((i) + first_bit) >> 5] >> (((i) + first_bit) & 31)) & 1u)
 #define DEMAND(i) (wanted[(i) + first_bit])
-        /* the resident tiles this round wanted are the most recently used */
-        for (i = 0; i < n; i++)
+        /* the resident tiles this round wanted are the most recently used; the ones this
+         * thread brought in last time have had their round */
+        for (i = 0; i < n; i++) {
                 if (DEMAND(i) && (s->tile[i] != NULL)) s->stamp[i] = ++s->clock;
+                if (s->owner[i] == &t_me) s->owner[i] = NULL;
+        }
+        /* First WHO comes and who goes, decided one tile after the other as the reference
+         * would meet them -- then the tiles that go, go, and those that come are read side
+         * by side (stack_load_tiles). */
+        char * here = malloc((size_t)(n ? n : 1));  /* resident, as the plan proceeds */
+        int * come = malloc((size_t)(n ? n : 1) * sizeof(*come));
+        if ((here == NULL) || (come == NULL)) {
+                free(here), free(come);
+                snprintf(message, size, "could not allocate memory");
+                return -TURTLE_RETURN_MEMORY_ERROR;
+        }
+        int resident = s->n_loaded;
+        for (i = 0; i < n; i++) here[i] = (s->tile[i] != NULL);
         for (;;) {
                 /* the next tile to bring in: one of the first item's, else the one
                  * in most demand */
                 int want = -1, first = 0;
                 for (i = 0; i < n; i++) {
-                        if ((s->tile[i] != NULL) || (s->path[i] == NULL) || !DEMAND(i)) continue;
+                        if (here[i] || (s->path[i] == NULL) || !DEMAND(i)) continue;
                         if (FIRST(i)) {
                                 want = i, first = 1;
                                 break;
@@ -341,12 +485,13 @@ static int stack_page_in(struct turtle_stack * s, const unsigned * wanted,
                         if ((want < 0) || (DEMAND(i) > DEMAND(want))) want = i;
                 }
                 if (want < 0) break;
-                if (s->n_loaded >= budget) {
+                if (resident >= budget) {
                         /* who goes: the tile in least demand, the least recently
-                         * wanted of those; never one of the first item's */
+                         * wanted of those; never one of the first item's, nor one
+                         * that this round brings in */
                         int out = -1;
                         for (i = 0; i < n; i++) {
-                                if ((s->tile[i] == NULL) || FIRST(i)) continue;
+                                if (!here[i] || (s->tile[i] == NULL) || FIRST(i) || (s->owner[i] != NULL)) continue;
                                 if ((out < 0) || (DEMAND(i) < DEMAND(out)) ||
                                     ((DEMAND(i) == DEMAND(out)) && (s->stamp[i] < s->stamp[out])))
                                         out = i;
@@ -355,15 +500,22 @@ static int stack_page_in(struct turtle_stack * s, const unsigned * wanted,
                          * whatever has to go -- or nothing, if all that is in memory is
                          * its own (the stack is trimmed when the call ends) */
                         if (!first && ((out < 0) || (DEMAND(out) >= DEMAND(want)))) break;
-                        if (out >= 0) stack_drop_tile(s, out);
+                        if (out >= 0) here[out] = 0, resident--;
                 }
-                const int rc = stack_load_tile(s, want, message, size);
-                if (rc != TURTLE_RETURN_SUCCESS) return -rc;
-                loaded++;
+                here[want] = 1, resident++;
+                come[loaded++] = want;
         }
+        for (i = 0; i < n; i++)
+                if (!here[i] && (s->tile[i] != NULL)) stack_drop_tile(s, i);
+        int rc = TURTLE_RETURN_SUCCESS;
+        for (i = 0; (i < loaded) && (rc == TURTLE_RETURN_SUCCESS); i += TAMD_STAGE_SLOTS)
+                rc = stack_load_tiles(s, come + i, (loaded - i < TAMD_STAGE_SLOTS) ? loaded - i : TAMD_STAGE_SLOTS,
+                    message, size);
+        for (i = 0; (rc == TURTLE_RETURN_SUCCESS) && (i < loaded); i++) s->owner[come[i]] = &t_me;
+        free(here), free(come);
 #undef FIRST
 #undef DEMAND
-        return loaded;
+        return (rc == TURTLE_RETURN_SUCCESS) ? loaded : -rc;
 }
 
 /* [ref stack.c:257-297]: bring tiles into memory, in directory order, until the

@@ -10,6 +10,8 @@
  */
 #include "host.h"
 
+#include <time.h>
+
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
@@ -488,8 +490,12 @@ static int stepper_rounds(struct turtle_stepper * stepper, long n, stepper_round
         if (rc != 0) return (rc < 0) ? TURTLE_RETURN_LIBRARY_ERROR : rc;
         if (stepper_is_paged(stepper) && tamd_pager_begin(&pager, n, stepper->n_table))
                 return TURTLE_RETURN_LIBRARY_ERROR;
+        static int trace_rounds = -1; /* TURTLE_AMD_PAGING_TRACE=1: the time of each round, to stderr */
+        if (trace_rounds < 0) trace_rounds = (getenv("TURTLE_AMD_PAGING_TRACE") != NULL);
         for (;;) {
                 struct tamd_paging pg;
+                struct timespec t0, t1, t2, t3;
+                if (trace_rounds) clock_gettime(CLOCK_MONOTONIC, &t0);
                 /* tables and launches of a round: nothing they point at may go meanwhile */
                 tamd_geometry_use_begin();
                 rc = tamd_stepper_flatten(stepper, message, size);
@@ -499,15 +505,30 @@ static int stepper_rounds(struct turtle_stepper * stepper, long n, stepper_round
                         rc = TURTLE_RETURN_LIBRARY_ERROR;
                 tamd_geometry_use_end();
                 if (rc != 0) break;
+                if (trace_rounds) clock_gettime(CLOCK_MONOTONIC, &t1);
                 unsigned long long faulted = 0;
                 if (tamd_pager_collect(&pager, &faulted)) {
                         rc = TURTLE_RETURN_LIBRARY_ERROR;
                         break;
                 }
-                if (faulted == 0) break;
+                if (trace_rounds) clock_gettime(CLOCK_MONOTONIC, &t2);
+                if (faulted == 0) {
+                        if (trace_rounds)
+                                fprintf(stderr, "[paging] round %d: tables+launch %.2f ms, kernels %.2f ms, done\n", pager.rounds,
+                                    1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec),
+                                    1e3 * (t2.tv_sec - t1.tv_sec) + 1e-6 * (t2.tv_nsec - t1.tv_nsec));
+                        break;
+                }
                 int code = 0;
                 const int got = stepper_page_in(stepper, pager.wanted, pager.pinned, &code,
                     message, size);
+                if (trace_rounds) {
+                        clock_gettime(CLOCK_MONOTONIC, &t3);
+                        fprintf(stderr, "[paging] round %d: tables+launch %.2f ms, kernels %.2f ms, %llu items wait, %d tiles in %.2f ms\n",
+                            pager.rounds, 1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec),
+                            1e3 * (t2.tv_sec - t1.tv_sec) + 1e-6 * (t2.tv_nsec - t1.tv_nsec), faulted, got,
+                            1e3 * (t3.tv_sec - t2.tv_sec) + 1e-6 * (t3.tv_nsec - t2.tv_nsec));
+                }
                 if (got < 0) {
                         rc = code;
                         break;

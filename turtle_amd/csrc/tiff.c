@@ -184,34 +184,43 @@ int tamd_tiff_probe(const char * path, struct turtle_map * m)
         return TURTLE_RETURN_SUCCESS;
 }
 
-int tamd_tiff_read(const char * path, struct turtle_map * m)
+/* grid rows iy0 .. iy1 - 1 (image row `row`, from the north, is grid row ny - 1 - row) */
+int tamd_tiff_read_rows(const char * path, struct turtle_map * m, int iy0, int iy1)
 {
         struct tiff_file t;
         int rc = tiff_open(path, &t);
         if (rc != TURTLE_RETURN_SUCCESS) return rc;
         const size_t nx = t.width;
-        uint32_t row = 0, strip;
-        for (strip = 0; (strip < t.n_strips) && (rc == TURTLE_RETURN_SUCCESS); strip++) {
-                uint32_t offset;
-                if (strip_offset(&t, strip, &offset) || (fseek(t.fid, offset, SEEK_SET) != 0)) {
-                        rc = TURTLE_RETURN_BAD_FORMAT + 100;
-                        break;
-                }
-                uint32_t r;
-                for (r = 0; (r < t.rows_per_strip) && (row < t.height); r++, row++) {
-                        /* image row `row` (from the north) is grid row ny-1-row */
-                        uint16_t * dst = m->nodes + ((size_t)t.height - 1 - row) * nx;
-                        if (fread(dst, sizeof(*dst), nx, t.fid) != nx) {
+        uint32_t row, in_strip = 0xffffffffu;
+        for (row = t.height - (uint32_t)iy1; (row < t.height - (uint32_t)iy0) && (rc == TURTLE_RETURN_SUCCESS);
+             row++) {
+                const uint32_t strip = row / t.rows_per_strip;
+                if (strip != in_strip) {
+                        uint32_t offset;
+                        if (strip_offset(&t, strip, &offset) ||
+                            (fseek(t.fid, (long)(offset + (size_t)(row % t.rows_per_strip) * nx * sizeof(uint16_t)),
+                                 SEEK_SET) != 0)) {
                                 rc = TURTLE_RETURN_BAD_FORMAT + 100;
                                 break;
                         }
-                        if (t.swap) {
-                                size_t i;
-                                for (i = 0; i < nx; i++)
-                                        dst[i] = (uint16_t)((dst[i] >> 8) | (dst[i] << 8));
-                        }
+                        in_strip = strip;
+                }
+                uint16_t * dst = m->nodes + ((size_t)t.height - 1 - row) * nx;
+                if (fread(dst, sizeof(*dst), nx, t.fid) != nx) {
+                        rc = TURTLE_RETURN_BAD_FORMAT + 100;
+                        break;
+                }
+                if (t.swap) {
+                        size_t i;
+                        for (i = 0; i < nx; i++)
+                                dst[i] = (uint16_t)((dst[i] >> 8) | (dst[i] << 8));
                 }
         }
         fclose(t.fid);
         return rc;
+}
+
+int tamd_tiff_read(const char * path, struct turtle_map * m)
+{
+        return tamd_tiff_read_rows(path, m, 0, m->ny);
 }
