@@ -200,17 +200,24 @@ class Terrain:
                 shutil.rmtree(self.hgt_dir, ignore_errors=True)
 
 
-def parity_counts(index, length, ref_index, ref_length):
-    """identical medium, |dL| / L <= 1e-6; the rays that miss are COUNTED"""
+def parity_counts(index, length, ref_index, ref_length, steps=None, ref_steps=None):
+    """identical medium, |dL| / L <= 1e-6; the rays that miss are COUNTED, and so are
+    the rays whose step count differs (a ray grazing a surface within 1e-9 m may take one more
+    or less)"""
     index, ref_index = np.asarray(index), np.asarray(ref_index)
     flipped = index[:, 0] != ref_index[:, 0]
     with np.errstate(invalid="ignore", divide="ignore"):
         rel = np.abs(np.asarray(length) - ref_length) / np.maximum(np.abs(ref_length), 1e-300)
     rel = np.where(np.isfinite(rel), rel, 0.0)
-    return {"rays": int(index.shape[0]), "medium_mismatch": int(flipped.sum()),
-            "beyond_1e-6": int((~flipped & (rel > 1e-6)).sum()),
-            "max_rel_path_length": float(rel[~flipped].max(initial=0.0)),
-            "checker": "oracle/ C restatement (reference arithmetic, exact transform), same rays"}
+    out = {"rays": int(index.shape[0]), "medium_mismatch": int(flipped.sum()),
+           "beyond_1e-6": int((~flipped & (rel > 1e-6)).sum()),
+           "max_rel_path_length": float(rel[~flipped].max(initial=0.0)),
+           "checker": "oracle/ C restatement (reference arithmetic, exact transform), same rays"}
+    if steps is not None and ref_steps is not None:
+        ds = np.abs(np.asarray(steps).astype(np.int64) - np.asarray(ref_steps).astype(np.int64))
+        out["step_count_mismatch"] = int((ds != 0).sum())
+        out["max_step_count_difference"] = int(ds.max(initial=0))
+    return out
 
 
 def cpu_baseline(terrain, pos, d, cores):
@@ -504,7 +511,8 @@ def run_workload(name, args, env, headline):
             else:
                 cpu, res = cpu_baseline(terrain, p_host, d_host, cores)
                 out["parity"] = parity_counts(index[:m].cpu().numpy(), length[:m].cpu().numpy(),
-                                              res["index"], res["length"])
+                                              res["index"], res["length"], nsteps[:m].cpu().numpy(),
+                                              res["n_steps"])
                 out["cpu_baseline"] = cpu_baseline_entry(cpu, cores, m)
     terrain.close()
     return out

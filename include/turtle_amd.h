@@ -284,12 +284,21 @@ TURTLE_API int turtle_amd_compute_units(void);
  *   FAST    (default) the same algorithm with shared reciprocals, rsqrt-based
  *           roots, one polynomial arctangent and FMAs: ~3x fewer instructions
  *           per sample; coordinates differ from STRICT by a few ulp (<= 3e-9 m
- *           in altitude), path lengths by <= 5e-8 relative.  In
- *           turtle_stepper_trace_n a long ray samples a cubic Taylor line of
- *           the transform along its path (truncation <= 2e-10 m near a
- *           boundary) and a crossing is located inside the reference's bracket
- *           by false position rather than by halving: the same end point to
- *           1e-8 m, the same medium and step count.
+ *           in altitude).  In turtle_stepper_trace_n a long ray samples a cubic
+ *           Taylor line of the transform along its path (truncation <= 2e-10 m
+ *           near a boundary), advances its position with one fused operation a
+ *           step, and every crossing of the batch is located afterwards, in a
+ *           kernel of its own, inside the reference's bracket by false position
+ *           rather than by halving (the end point agrees to 1e-8 m).
+ *           WHAT IS GUARANTEED (and tested, with no allowance, against the
+ *           reference's golden vectors and the CPU restatement at full size):
+ *           the same medium index; the path length within 1e-6 relative
+ *           (measured: <= 5e-8 on every test, 1.6e-8 on C2's million rays); the
+ *           step count equal, or off by one on a ray that grazes a surface
+ *           within 1e-9 m (measured: 4 rays of C2's million).  The one ray kind
+ *           outside the length bar is a ray that reaches no boundary before
+ *           max_steps: its "length" is a sum of clearance-sized steps, not a
+ *           distance (tests/test_gpu_parity.py names the one the suite has).
  * Both are checked against the reference's golden vectors at the 1e-6 bar.
  * Every other kernel (elevation, position, step, the other ecef transforms)
  * is always STRICT. */
@@ -413,16 +422,18 @@ enum turtle_amd_trace_flags {
  * [shape of examples/example-stepper.c:128-140].  Outputs per ray: final
  * index pair, path length = sum of the step lengths, number of steps; the
  * position is advanced in place.  Rays that start outside the data take 0
- * steps and report index[0] = -1.  length/n_steps may be NULL. */
+ * steps and report index[0] = -1.  length/n_steps may be NULL: which outputs a
+ * caller asks for changes neither the kernels that run nor a bit of the others. */
 TURTLE_API enum turtle_return turtle_stepper_trace_n(
     struct turtle_stepper * stepper, long n, double * position /* [n][3] */,
     const double * direction /* [n][3] */, int max_steps,
     int * index /* [n][2] */, double * length, int * n_steps, int flags,
     int space);
 
-/* Totals of the LAST trace_n call on this stepper, accumulated on the device:
- * stats[0] rays, [1] steps, [2] samples (transform + layer lookup), [3]
- * rays that stopped at max_steps.  Synchronises the stream. */
+/* Totals of the LAST trace_n or scatter_n call on this stepper, accumulated on the
+ * device: stats[0] rays, [1] steps, [2] samples (transform + layer lookup; the
+ * same from run to run), [3] rays that stopped at max_steps.  Synchronises the
+ * stream. */
 TURTLE_API enum turtle_return turtle_stepper_trace_stats(
     struct turtle_stepper * stepper, unsigned long long stats[4]);
 

@@ -33,6 +33,9 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
@@ -2932,6 +2935,17 @@ struct Ctx {
 };
 static thread_local char g_error[512] = "";
 static thread_local Ctx g_ctx;
+/* A thread that ends without turtle_amd_thread_release() (a pool's worker, an OpenMP
+ * thread) gives back its stream, arena, blocks and pinned buffer here -- while the
+ * process lives: at process exit the HIP runtime may already be gone, and the
+ * main thread's context is left to it. */
+static thread_local struct CtxGuard {
+        bool armed = false; /* (set by tamd_dev_select on any thread but the main one) */
+        ~CtxGuard()
+        {
+                if (armed) g_ctx.release();
+        }
+} g_ctx_guard;
 #define g_stream (g_ctx.stream)
 #define g_cus (g_ctx.cus)
 #define g_math_strict (g_ctx.math_strict)
@@ -2988,6 +3002,7 @@ extern "C" int tamd_dev_select(int device)
         g_ctx.release();
         HIP_TRY(hipSetDevice(device));
         g_ctx.device = device;
+        g_ctx_guard.armed = ((long)syscall(SYS_gettid) != (long)getpid()); /* not the main thread: see CtxGuard */
         g_ctx.cus = prop.multiProcessorCount;
         HIP_TRY(hipStreamCreateWithFlags(&g_ctx.own_stream, hipStreamNonBlocking));
         g_ctx.stream = g_ctx.own_stream;
@@ -3036,13 +3051,20 @@ extern "C" int tamd_dev_sync(void)
 
 /* every stream of `device` (before memory that other threads' launches may still
  * read is freed); leaves the calling thread on its own device */
+/* Every stream of that device has drained (non-zero: it could not be told -- the
+ * caller then LEAKS what it meant to free there, rather than free memory that a
+ * launch may still read).  The calling thread is back on its own device on every
+ * path. */
 extern "C" int tamd_dev_sync_device(int device)
 {
         if (device < 0) return 0;
-        HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipDeviceSynchronize());
-        if (g_ctx.device >= 0) HIP_TRY(hipSetDevice(g_ctx.device));
-        return 0;
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if ((g_ctx.device >= 0) && (g_ctx.device != device)) {
+                const hipError_t back = hipSetDevice(g_ctx.device);
+                if (e == hipSuccess) e = back;
+        }
+        return (e == hipSuccess) ? 0 : fail("tamd_dev_sync_device", e);
 }
 
 extern "C" int tamd_dev_malloc(void ** ptr, size_t bytes)

@@ -62,8 +62,9 @@ void tamd_map_release(struct turtle_map * m)
         int d;
         for (d = 0; d < TAMD_MAX_DEVICES; d++) {
                 if (m->d_nodes[d] == NULL) continue;
-                tamd_dev_sync_device(d);
-                tamd_dev_free_on(d, m->d_nodes[d]);
+                /* (a device that cannot be waited for: the copy is leaked, not freed
+                 * under a launch that may still read it) */
+                if (tamd_dev_sync_device(d) == 0) tamd_dev_free_on(d, m->d_nodes[d]);
                 m->d_nodes[d] = NULL;
         }
         m->d_fresh = 0;

@@ -21,11 +21,14 @@
 /* what the stepper holds in HBM, on the device it was last used on */
 static void stepper_release_device(struct turtle_stepper * s)
 {
+        int drained = 1;
         if ((s->d_tables != NULL) || (s->d_stats != NULL) || (s->d_parked != NULL))
-                tamd_dev_sync_device(s->device);
-        tamd_dev_free_on(s->device, s->d_tables);
-        tamd_dev_free_on(s->device, s->d_stats);
-        tamd_dev_free_on(s->device, s->d_parked);
+                drained = (tamd_dev_sync_device(s->device) == 0);
+        if (drained) { /* else: leaked, rather than freed under a launch that may still read it */
+                tamd_dev_free_on(s->device, s->d_tables);
+                tamd_dev_free_on(s->device, s->d_stats);
+                tamd_dev_free_on(s->device, s->d_parked);
+        }
         s->d_tables = NULL, s->d_stats = NULL, s->d_parked = NULL, s->d_scratch_ds = NULL;
         s->d_tables_size = 0, s->parked_capacity = 0, s->epoch = 0;
 }
@@ -774,13 +777,16 @@ enum turtle_return turtle_stepper_scatter_n(struct turtle_stepper * stepper, lon
         int rc = 0, k;
         if (start) {
                 rc = stepper_rounds(stepper, n, &walk_start_round, &a, message, sizeof(message));
-                if ((rc == 0) && (tamd_dev_zero(a.length, nb) || tamd_dev_zero(a.steps, n * sizeof(int)) ||
-                        tamd_dev_zero(stepper->d_stats, 4 * sizeof(*stepper->d_stats))))
+                if ((rc == 0) && (tamd_dev_zero(a.length, nb) || tamd_dev_zero(a.steps, n * sizeof(int))))
                         rc = TURTLE_RETURN_LIBRARY_ERROR;
         } else if (stepper->d_stats == NULL) {
                 rc = tamd_stepper_flatten(stepper, message, sizeof(message));
                 if (rc < 0) rc = TURTLE_RETURN_LIBRARY_ERROR;
         }
+        /* the counters are those of THIS call (turtle_stepper_trace_stats), whatever the
+         * stepper's last batch left there */
+        if ((rc == 0) && tamd_dev_zero(stepper->d_stats, 4 * sizeof(*stepper->d_stats)))
+                rc = TURTLE_RETURN_LIBRARY_ERROR;
         /* every tile resident: the whole walk in one launch, the rays' state in
          * registers (k_walk); else generation by generation, each in rounds over the
          * rays that wait for a tile (TURTLE_AMD_WALK=steps: that form always) */
