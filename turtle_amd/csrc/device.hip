@@ -2565,10 +2565,14 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
 #ifndef TRACE_LINED_WAVES
 #define TRACE_LINED_WAVES 3
 #endif
+#ifndef TRACE_A_WAVES
+#define TRACE_A_WAVES 1
+#endif
 template <int MODE, bool FAST, bool MODEL, bool PAGED>
 constexpr int trace_waves()
 {
-        return (FAST && MODEL && !PAGED && (MODE != TAMD_MODE_GENERIC)) ? TRACE_LINED_WAVES : 1;
+        return (FAST && MODEL && !PAGED && (MODE != TAMD_MODE_GENERIC)) ? TRACE_LINED_WAVES :
+               (FAST && !MODEL && !PAGED && (MODE != TAMD_MODE_GENERIC)) ? TRACE_A_WAVES : 1;
 }
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED, bool CROSS>
