@@ -2,17 +2,22 @@
  * trace_rays.c -- a plain C caller of libturtle_amd.
  *
  * Builds a small geodetic map with the reference's own API, then traces rays
- * to their first boundary twice: with the reference's per-ray loop of scalar
+ * to their first boundary three ways: with the reference's per-ray loop of scalar
  * turtle_stepper_step calls (the shape of the reference's
- * examples/example-stepper.c:116-140), and with one turtle_stepper_trace_n
- * call.  Prints both and exits non-zero if they disagree.
+ * examples/example-stepper.c:116-140) answered by the kernels, a launch a call
+ * (the default; a few rays only); the same loop with the scalar calls answered
+ * on the host (turtle_amd_scalar_set: for callers that keep that loop; all the
+ * rays, timed); and with one turtle_stepper_trace_n call.  Prints them and exits
+ * non-zero if they disagree.
  *
  *   cc -Iinclude examples/trace_rays.c -Lturtle_amd -lturtle_amd -lm \
  *      -Wl,-rpath,$PWD/turtle_amd -o trace_rays
  */
+#define _POSIX_C_SOURCE 200809L
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 
 #include "turtle.h" /* the drop-in name; forwards to turtle_amd.h */
 
@@ -73,6 +78,33 @@ int main(void)
                 scalar_length[r] = total, scalar_medium[r] = idx[0], scalar_steps[r] = n;
         }
 
+        /* (1b) the same loop, the scalar calls answered on the host: every ray */
+        static double host_length[N_RAYS];
+        static int host_medium[N_RAYS], host_steps[N_RAYS];
+        turtle_amd_scalar_set(TURTLE_AMD_SCALAR_HOST);
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        long host_calls = 0;
+        for (r = 0; r < N_RAYS; r++) {
+                double p[3] = { position[r][0], position[r][1], position[r][2] };
+                int idx[2];
+                turtle_stepper_step(stepper, p, NULL, NULL, NULL, NULL, NULL, NULL, idx);
+                const int medium = idx[0];
+                double total = 0., ds;
+                int n = 0;
+                do {
+                        turtle_stepper_step(stepper, p, direction[r], NULL, NULL, NULL, NULL, &ds, idx);
+                        total += ds, n++;
+                } while ((idx[0] == medium) && (n < 100000));
+                host_length[r] = total, host_medium[r] = idx[0], host_steps[r] = n;
+                host_calls += n + 1;
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        turtle_amd_scalar_set(TURTLE_AMD_SCALAR_DEVICE);
+        const double host_ns = 1e9 * (double)(t1.tv_sec - t0.tv_sec) + (double)(t1.tv_nsec - t0.tv_nsec);
+        printf("scalar loop on the host: %ld calls of turtle_stepper_step, %.0f ns a call\n", host_calls,
+            host_ns / (double)host_calls);
+
         /* (2) one batch call for all rays */
         turtle_stepper_trace_n(stepper, N_RAYS, &position[0][0], &direction[0][0], 100000,
             &index[0][0], length, n_steps, 0, TURTLE_AMD_HOST);
@@ -88,6 +120,10 @@ int main(void)
                     index[r][0]);
                 if ((rel > 1e-9) || (scalar_medium[r] != index[r][0]) || (scalar_steps[r] != n_steps[r]))
                         bad++;
+        }
+        for (r = 0; r < N_RAYS; r++) { /* the host's loop against the kernels, every ray */
+                const double rel = fabs(length[r] - host_length[r]) / host_length[r];
+                if ((rel > 1e-9) || (host_medium[r] != index[r][0]) || (host_steps[r] != n_steps[r])) bad++;
         }
         printf("%d rays, %ld steps, %d hit the ground; %d disagreements\n", N_RAYS, steps, hits, bad);
 

@@ -302,6 +302,21 @@ TURTLE_API int turtle_amd_compute_units(void);
  * Both are checked against the reference's golden vectors at the 1e-6 bar.
  * Every other kernel (elevation, position, step, the other ecef transforms)
  * is always STRICT. */
+/* WHERE the scalar (one point a call) drop-in functions compute.  DEVICE (default):
+ * in the kernels, with n = 1 -- every call a launch and two copies, 20-35 us.  HOST:
+ * turtle_ecef_*, turtle_map_elevation, turtle_stack_elevation, turtle_client_elevation,
+ * turtle_stepper_step and turtle_stepper_position are answered by a host restatement of
+ * the same reference functions (turtle_amd/csrc/scalar.c; the reference's arithmetic
+ * with the exact transform, its `last`-sample cache, its tile list) on the host copies
+ * of the maps and tiles -- ~0.1 us a call, for callers that keep the reference's per-ray
+ * loop.  The batch calls (`_n`) run on the GPU whatever this says; a geometry with a
+ * projected map stays with the kernels; and a usable device is required either way:
+ * this is an option of a GPU library, not a fallback for machines without one.
+ * Process-wide; set it before the stepping starts. */
+enum turtle_amd_scalar { TURTLE_AMD_SCALAR_DEVICE = 0, TURTLE_AMD_SCALAR_HOST = 1 };
+TURTLE_API void turtle_amd_scalar_set(int mode);
+TURTLE_API int turtle_amd_scalar_get(void);
+
 enum turtle_amd_math { TURTLE_AMD_MATH_FAST = 0, TURTLE_AMD_MATH_STRICT = 1 };
 TURTLE_API void turtle_amd_math_set(int mode);
 TURTLE_API int turtle_amd_math_get(void);

@@ -199,6 +199,48 @@ def test_hgt_tile_traces(golden, tmp_path, math):
     m.destroy()
 
 
+def test_scalar_calls_on_the_host_agree_with_the_kernels(golden, tmp_path):
+    """turtle_amd_scalar_set(HOST): the drop-in scalar functions answered by the host restatement
+    (csrc/scalar.c) give what the kernels give -- the strict kernels to the last ulp of OCML's
+    trig, the fast ones at the parity bar -- over a map, two layers with a geoid, and a stack
+    that pages; and the batch calls do not care about the option."""
+    g = golden("c1_traces")
+    m = B.c1_map()
+    st = B.c1_stepper(m)
+    sel = slice(0, 200)
+    pos, d = g["position"][sel], g["direction"][sel]
+    TA.set_math("strict")
+    ref = st.trace(pos.copy(), d)
+    try:
+        TA.set_scalar("host")
+        assert TA.get_scalar() == "host"
+        again = st.trace(pos.copy(), d)          # a batch call: still the kernels
+        for key in ("index", "n_steps", "length", "position"):
+            assert np.array_equal(again[key], ref[key])
+        for r in range(200):
+            o = st.step_scalar(pos[r])
+            medium, p, total, k = o["index"][0], o["position"], 0.0, 0
+            while True:
+                o = st.step_scalar(p, d[r])
+                p, total, k = o["position"], total + o["step"], k + 1
+                if o["index"][0] != medium or k >= 100000:
+                    break
+            assert o["index"][0] == ref["index"][r, 0] and k == ref["n_steps"][r]
+            assert abs(total - ref["length"][r]) <= 1e-9 * ref["length"][r]
+            assert np.abs(p - ref["position"][r]).max() < 1e-6
+        # the reference's golden values, through the public scalar entry points
+        p0, di = st.position_scalar(g["lat"][0], g["lon"][0], 500.0)
+        assert np.array_equal(p0, g["position"][0]) and di == 0
+        z, inside = m.elevation_scalar(3.5, 45.5)
+        zk, ik = m.elevation(np.array([3.5]), np.array([45.5]))
+        assert inside == 1 and z == zk[0]
+    finally:
+        TA.set_scalar("device")
+        TA.set_math("fast")
+    st.destroy()
+    m.destroy()
+
+
 def test_outputs_not_asked_for_change_nothing(math):
     """A caller that wants no path lengths or step counts gets the same media and end points, to
     the bit, from the same kernels (the trace's own counters say so) as one that wants them."""

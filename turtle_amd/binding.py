@@ -181,6 +181,16 @@ def get_math():
     return "strict" if lib().turtle_amd_math_get() else "fast"
 
 
+def set_scalar(where):
+    """where the scalar (one point a call) drop-in functions compute: 'device' (default: the
+    kernels with n = 1) or 'host' (turtle_amd/csrc/scalar.c; enum turtle_amd_scalar)"""
+    lib().turtle_amd_scalar_set({"device": 0, "host": 1}[where])
+
+
+def get_scalar():
+    return "host" if lib().turtle_amd_scalar_get() else "device"
+
+
 # ---- ECEF -------------------------------------------------------------------
 
 def ecef_from_geodetic(latitude, longitude, elevation):

@@ -102,6 +102,10 @@ static void raise_void(turtle_function_t * caller)
 void turtle_ecef_from_geodetic(
     double latitude, double longitude, double elevation, double ecef[3])
 {
+        if (tamd_scalar_on_host()) { /* (the caller's option: scalar.c) */
+                tamd_h_from_geodetic(latitude, longitude, elevation, ecef);
+                return;
+        }
         if (run4(&k_from_geodetic, 1, &latitude, &longitude, &elevation, NULL, 3, ecef,
                 TURTLE_AMD_HOST))
                 raise_void((turtle_function_t *)&turtle_ecef_from_geodetic);
@@ -110,6 +114,10 @@ void turtle_ecef_from_geodetic(
 void turtle_ecef_from_horizontal(double latitude, double longitude, double azimuth,
     double elevation, double direction[3])
 {
+        if (tamd_scalar_on_host()) {
+                tamd_h_from_horizontal(latitude, longitude, azimuth, elevation, direction);
+                return;
+        }
         if (run4(&tamd_k_ecef_from_horizontal, 1, &latitude, &longitude, &azimuth,
                 &elevation, 3, direction, TURTLE_AMD_HOST))
                 raise_void((turtle_function_t *)&turtle_ecef_from_horizontal);
@@ -118,6 +126,14 @@ void turtle_ecef_from_horizontal(double latitude, double longitude, double azimu
 void turtle_ecef_to_geodetic(
     const double ecef[3], double * latitude, double * longitude, double * altitude)
 {
+        if (tamd_scalar_on_host()) {
+                double la, lo, al;
+                tamd_h_to_geodetic(ecef, &la, &lo, &al);
+                if (latitude != NULL) *latitude = la;
+                if (longitude != NULL) *longitude = lo;
+                if (altitude != NULL) *altitude = al;
+                return;
+        }
         struct tamd_stage st;
         void *de, *dla, *dlo, *dal;
         if (tamd_stage_begin(&st, TURTLE_AMD_HOST, 6 * sizeof(double)) ||
@@ -135,6 +151,10 @@ void turtle_ecef_to_geodetic(
 void turtle_ecef_to_horizontal(double latitude, double longitude,
     const double direction[3], double * azimuth, double * elevation)
 {
+        if (tamd_scalar_on_host()) {
+                tamd_h_to_horizontal(latitude, longitude, direction, azimuth, elevation);
+                return;
+        }
         struct tamd_stage st;
         void *dla, *dlo, *dd, *daz, *del;
         if (tamd_stage_begin(&st, TURTLE_AMD_HOST, 7 * sizeof(double)) ||

@@ -196,7 +196,18 @@ struct tamd_layer {
         int size, capacity;
 };
 
+/* the reference's `last` sample [ref src/turtle/stepper.h:93-98], for the scalar calls
+ * answered on the host (scalar.c) */
+struct tamd_host_sample {
+        int valid;
+        double position[3];
+        double latitude, longitude, altitude;
+        double elevation[2];
+        int index[2];
+};
+
 struct turtle_stepper {
+        struct tamd_host_sample last;
         struct tamd_data * data;
         int n_data, cap_data;
         struct tamd_layer * layers;
@@ -263,5 +274,26 @@ int tamd_stage_in(struct tamd_stage * st, const void * user, size_t bytes, void 
 int tamd_stage_out(struct tamd_stage * st, void * user, size_t bytes, void ** dev);
 int tamd_stage_fetch(struct tamd_stage * st, void * user, size_t bytes, const void * dev);
 int tamd_stage_end(struct tamd_stage * st);
+
+/* ---- the scalar entry points on the host (scalar.c; opt-in) ------------------- */
+int tamd_scalar_on_host(void);
+void tamd_h_from_geodetic(double latitude, double longitude, double elevation, double ecef[3]);
+void tamd_h_to_geodetic(const double ecef[3], double * latitude, double * longitude, double * altitude);
+void tamd_h_from_horizontal(double latitude, double longitude, double azimuth, double elevation,
+    double direction[3]);
+void tamd_h_to_horizontal(double latitude, double longitude, const double direction[3], double * azimuth,
+    double * elevation);
+int tamd_h_map_elevation(const struct turtle_map * map, double x, double y, double * z);
+int tamd_h_stack_elevation(struct turtle_stack * stack, double latitude, double longitude, double * z,
+    int * inside, char * message, size_t size);
+int tamd_h_stepper_takes(const struct turtle_stepper * stepper);
+int tamd_h_stepper_step(struct turtle_stepper * stepper, double * position, const double * direction,
+    double * latitude, double * longitude, double * altitude, double * elevation, double * step_length,
+    int * index, char * message, size_t size);
+int tamd_h_stepper_position(struct turtle_stepper * stepper, double latitude, double longitude,
+    double height, int layer_index, double * position, int * data_index, char * message, size_t size);
+/* stack.c: one tile into memory for the host path, the least recently used going beyond the
+ * stack's size [ref stack.c:399-450]; an enum turtle_return */
+int tamd_stack_host_load(struct turtle_stack * stack, int slot, char * message, size_t size);
 
 #endif

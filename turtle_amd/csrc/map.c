@@ -430,7 +430,9 @@ enum turtle_return turtle_map_elevation(const struct turtle_map * map, double x,
         TAMD_ERROR_INIT(&turtle_map_elevation);
         double z = 0.;
         int in = 0;
-        if (map_elevation_n((struct turtle_map *)map, 1, &x, &y, &z, &in, TURTLE_AMD_HOST))
+        if (tamd_scalar_on_host()) /* (the caller's option: scalar.c) */
+                in = tamd_h_map_elevation(map, x, y, &z);
+        else if (map_elevation_n((struct turtle_map *)map, 1, &x, &y, &z, &in, TURTLE_AMD_HOST))
                 return TAMD_RAISE_DEVICE();
         if (in) *elevation = z; /* an outside point leaves *elevation untouched */
         if (inside != NULL)

@@ -518,6 +518,38 @@ static int stack_page_in(struct turtle_stack * s, const unsigned * wanted,
         return (rc == TURTLE_RETURN_SUCCESS) ? loaded : -rc;
 }
 
+/* One tile for the host's scalar path (scalar.c), as the reference loads one [ref
+ * stack.c:428-446]: beyond the stack's size the least recently used tiles go first
+ * (none that a thread has just paged in for its round). */
+int tamd_stack_host_load(struct turtle_stack * s, int slot, char * message, size_t size)
+{
+        const int n = s->latitude_n * s->longitude_n, budget = tamd_stack_budget(s);
+        if ((s->lock != NULL) && (s->lock() != 0)) {
+                snprintf(message, size, "could not acquire the lock");
+                return TURTLE_RETURN_LOCK_ERROR;
+        }
+        tamd_geometry_write_begin();
+        int rc = TURTLE_RETURN_SUCCESS;
+        if (s->tile[slot] == NULL) {
+                while (s->n_loaded >= budget) {
+                        int i, out = -1;
+                        for (i = 0; i < n; i++) {
+                                if ((s->tile[i] == NULL) || (s->owner[i] != NULL)) continue;
+                                if ((out < 0) || (s->stamp[i] < s->stamp[out])) out = i;
+                        }
+                        if (out < 0) break;
+                        stack_drop_tile(s, out);
+                }
+                rc = stack_load_tiles(s, &slot, 1, message, size);
+        }
+        tamd_geometry_write_end();
+        if ((s->unlock != NULL) && (s->unlock() != 0) && (rc == TURTLE_RETURN_SUCCESS)) {
+                snprintf(message, size, "could not release the lock");
+                rc = TURTLE_RETURN_UNLOCK_ERROR;
+        }
+        return rc;
+}
+
 /* [ref stack.c:257-297]: bring tiles into memory, in directory order, until the
  * stack is full (they go on to HBM at the next device call) */
 enum turtle_return turtle_stack_load(struct turtle_stack * stack)
@@ -712,8 +744,10 @@ enum turtle_return tamd_stack_elevation_scalar(struct turtle_stack * stack,
         double z = 0.;
         int in = 0;
         char message[4200];
-        const int rc = stack_elevation_n(stack, 1, &latitude, &longitude, &z, &in,
-            TURTLE_AMD_HOST, message, sizeof(message));
+        const int rc = tamd_scalar_on_host() ? /* (the caller's option: scalar.c) */
+            tamd_h_stack_elevation(stack, latitude, longitude, &z, &in, message, sizeof(message)) :
+            stack_elevation_n(stack, 1, &latitude, &longitude, &z, &in, TURTLE_AMD_HOST, message,
+                sizeof(message));
         if (rc < 0) return TAMD_RAISE_DEVICE();
         if (rc > 0) return TAMD_RAISE((enum turtle_return)rc, "%s", message);
         *elevation = in ? z : 0.;

@@ -128,6 +128,7 @@ static int push_meta(struct turtle_stepper * s, int data, double offset)
         l->meta[l->size].data = data;
         l->meta[l->size].offset = offset;
         l->size++;
+        s->last.valid = 0; /* (the host's cached sample: scalar.c) */
         tamd_geometry_changed();
         return 0;
 }
@@ -199,6 +200,7 @@ enum turtle_return turtle_stepper_add_flat(struct turtle_stepper * stepper, doub
 void turtle_stepper_geoid_set(struct turtle_stepper * stepper, struct turtle_map * geoid)
 {
         stepper->geoid = geoid;
+        stepper->last.valid = 0;
         tamd_geometry_changed();
 }
 
@@ -218,7 +220,8 @@ void turtle_stepper_range_set(struct turtle_stepper * stepper, double range)
 }
 
 /* nothing is cached between calls, so there is no history to reset */
-void turtle_stepper_reset(struct turtle_stepper * stepper) { (void)stepper; }
+/* [ref stepper.c:662-672]: forgets the cached sample (the scalar calls on the host keep one) */
+void turtle_stepper_reset(struct turtle_stepper * stepper) { stepper->last.valid = 0; }
 
 double turtle_stepper_slope_get(const struct turtle_stepper * stepper)
 {
@@ -915,6 +918,14 @@ enum turtle_return turtle_stepper_step(struct turtle_stepper * stepper, double *
     double * elevation, double * step, int * index)
 {
         TAMD_ERROR_INIT(&turtle_stepper_step);
+        if (tamd_scalar_on_host() && tamd_h_stepper_takes(stepper)) { /* (the caller's option: scalar.c) */
+                char message[4200];
+                const int rc = tamd_h_stepper_step(stepper, position, direction, latitude, longitude,
+                    altitude, elevation, step, index, message, sizeof(message));
+                if (rc == TURTLE_RETURN_DOMAIN_ERROR) return TAMD_RAISE(TURTLE_RETURN_DOMAIN_ERROR, "no valid data");
+                if (rc != 0) return TAMD_RAISE((enum turtle_return)rc, "%s", message);
+                return TURTLE_RETURN_SUCCESS;
+        }
         int idx[2] = { -1, -1 };
         const enum turtle_return rc = step_n(&error_, stepper, 1, position, direction,
             latitude, longitude, altitude, elevation, step, idx, 0, TURTLE_AMD_HOST);
@@ -934,6 +945,17 @@ enum turtle_return turtle_stepper_position(struct turtle_stepper * stepper, doub
         if ((layer_index < 0) || (layer_index >= stepper->n_layers))
                 return TAMD_RAISE(TURTLE_RETURN_DOMAIN_ERROR, "no valid data");
         int di = -1;
+        if (tamd_scalar_on_host() && tamd_h_stepper_takes(stepper)) { /* (the caller's option: scalar.c) */
+                char message[4200];
+                const int rc = tamd_h_stepper_position(stepper, latitude, longitude, height, layer_index,
+                    position, &di, message, sizeof(message));
+                if (rc != 0) return TAMD_RAISE((enum turtle_return)rc, "%s", message);
+                if (data_index != NULL)
+                        *data_index = di;
+                else if (di < 0)
+                        return TAMD_RAISE(TURTLE_RETURN_DOMAIN_ERROR, "no valid data");
+                return TURTLE_RETURN_SUCCESS;
+        }
         const enum turtle_return rc = turtle_stepper_position_n(stepper, 1, &latitude,
             &longitude, &height, layer_index, position, &di, TURTLE_AMD_HOST);
         if (rc != TURTLE_RETURN_SUCCESS) return rc;
