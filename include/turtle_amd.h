@@ -12,10 +12,13 @@
  *      [ref include/turtle.h:LINE] and the implementation it restates as
  *      [impl src/turtle/FILE.c:LINE] (paths under the reference tree).
  *      These are scalar calls: each one runs the same device kernels as the
- *      batch form with n = 1 and therefore costs one kernel launch.  There is
- *      NO CPU implementation of the arithmetic in this library; without a
- *      usable gfx950 device every computing entry point fails with
- *      TURTLE_RETURN_LIBRARY_ERROR through the error handler.
+ *      batch form with n = 1 and therefore costs one kernel launch -- unless
+ *      the caller asks for them to be answered on the host
+ *      (turtle_amd_scalar_set: a restatement of the reference's one-point
+ *      functions for callers that keep its per-ray loop; off by default).
+ *      Without a usable gfx950 device every computing entry point fails with
+ *      TURTLE_RETURN_LIBRARY_ERROR through the error handler, whatever that
+ *      option says: nothing in this library stands in for a missing GPU.
  *
  *  (2) BATCH EXTENSION (suffix _n, prefix turtle_amd_): the same operations on
  *      n independent rays/points per call, which is what a GPU is for.  The

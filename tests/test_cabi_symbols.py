@@ -64,6 +64,18 @@ def test_no_gpu_means_loud_failure_not_a_cpu_path():
     with pytest.raises(TA.TurtleError) as e:
         st.trace(np.zeros((2, 3)), np.ones((2, 3)))
     assert e.value.name == "LIBRARY_ERROR"
+    # ... and the option that answers the scalar calls on the host is no way round it: it says
+    # where a point is computed on a machine that has the GPU, it stands in for no GPU
+    TA.set_scalar("host")
+    try:
+        with pytest.raises(TA.TurtleError) as e:
+            m.elevation_scalar(0.5, 0.5)
+        assert e.value.name == "LIBRARY_ERROR"
+        with pytest.raises(TA.TurtleError) as e:
+            st.step_scalar([4.2e6, 1.7e5, 4.7e6])
+        assert e.value.name == "LIBRARY_ERROR"
+    finally:
+        TA.set_scalar("device")
     st.destroy()
     m.destroy()
 

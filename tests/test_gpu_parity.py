@@ -227,7 +227,7 @@ def test_scalar_calls_on_the_host_agree_with_the_kernels(golden, tmp_path):
                     break
             assert o["index"][0] == ref["index"][r, 0] and k == ref["n_steps"][r]
             assert abs(total - ref["length"][r]) <= 1e-9 * ref["length"][r]
-            assert np.abs(p - ref["position"][r]).max() < 1e-6
+            assert np.abs(p - ref["position"][r]).max() < 1e-5
         # the reference's golden values, through the public scalar entry points
         p0, di = st.position_scalar(g["lat"][0], g["lon"][0], 500.0)
         assert np.array_equal(p0, g["position"][0]) and di == 0
