@@ -8,7 +8,13 @@
  *   gcc -std=gnu99 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include \
  *       examples/multi_gpu_tally.c -Lturtle_amd -lturtle_amd -L/opt/rocm/lib \
  *       -lrccl -lamdhip64 -lpthread -lm -Wl,-rpath,$PWD/turtle_amd -o multi_gpu_tally
- *   ./multi_gpu_tally [n_gpus [rays_per_gpu]]
+ *   ./multi_gpu_tally [n_gpus [rays_per_gpu [share]]]
+ *
+ * `share` (any third argument): the ranks share the visible GPUs round robin -- two ranks on
+ * ONE device, to rehearse a communicator of more than one where there is one GPU.  RCCL (2.x
+ * of ROCm 7) refuses that at ncclCommInitAll ("invalid usage": a duplicate device), so this
+ * mode only shows that it does; the threads themselves run (tests/test_gpu_paging.py shares a
+ * device between four of them).
  *
  * Every rank ends with the same sums; rank 0 prints them, and checks them
  * against one more trace of ALL the rays on its own GPU (integer sums: equal
@@ -107,7 +113,7 @@ static void trace_and_tally(struct turtle_map * map, long first, long n, unsigne
 static void * worker(void * arg)
 {
         struct job * job = arg;
-        turtle_amd_device_set(job->rank); /* this THREAD's GPU from here on */
+        turtle_amd_device_set(job->rank % turtle_amd_device_count()); /* this THREAD's GPU from here on */
         unsigned long long * d_tally;
         CHECK(hipMalloc((void **)&d_tally, sizeof(job->tally)));
         CHECK(hipMemset(d_tally, 0, sizeof(job->tally)));
@@ -140,7 +146,8 @@ int main(int argc, char * argv[])
         int world = (argc > 1) ? atoi(argv[1]) : turtle_amd_device_count();
         const long n = (argc > 2) ? atol(argv[2]) : 200000;
         if (world < 1) world = 1;
-        if (world > turtle_amd_device_count()) {
+        const int share = (argc > 3);
+        if (!share && (world > turtle_amd_device_count())) {
                 fprintf(stderr, "%d GPUs asked for, %d visible\n", world, turtle_amd_device_count());
                 return EXIT_FAILURE;
         }
@@ -158,8 +165,14 @@ int main(int argc, char * argv[])
         int devices[16];
         ncclComm_t comms[16];
         int g;
-        for (g = 0; g < world; g++) devices[g] = g;
-        CHECK(ncclCommInitAll(comms, world, devices));
+        for (g = 0; g < world; g++) devices[g] = share ? g % turtle_amd_device_count() : g;
+        const int init = (int)ncclCommInitAll(comms, world, devices);
+        if (init != 0) {
+                fprintf(stderr, "ncclCommInitAll over devices");
+                for (g = 0; g < world; g++) fprintf(stderr, " %d", devices[g]);
+                fprintf(stderr, " failed: %s\n", ncclGetErrorString((ncclResult_t)init));
+                return EXIT_FAILURE;
+        }
         struct job jobs[16];
         pthread_t threads[16];
         for (g = 0; g < world; g++) {
