@@ -288,7 +288,7 @@ TURTLE_API int turtle_amd_compute_units(void);
  *           roots, one polynomial arctangent and FMAs: ~3x fewer instructions
  *           per sample; coordinates differ from STRICT by a few ulp (<= 3e-9 m
  *           in altitude).  In turtle_stepper_trace_n a long ray samples a cubic
- *           Taylor line of the transform along its path (truncation <= 2e-10 m
+ *           Taylor line of the transform along its path (truncation <= 1e-9 m
  *           near a boundary), advances its position with one fused operation a
  *           step, and every crossing of the batch is located afterwards, in a
  *           kernel of its own, inside the reference's bracket by false position

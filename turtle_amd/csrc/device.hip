@@ -259,7 +259,24 @@ __device__ __forceinline__ double f_atan2(double y, double x)
  * serves ~1000 samples.  Whether a sample comes from the line depends on the
  * ray alone (its own line and path parameter), never on its wave. */
 constexpr double kLineRange = 4000.; /* m, either side of the origin: hard limit */
-constexpr double kLineTolerance = 2e-10; /* see f_line_serves */
+/* The truncation a line is allowed near a boundary: a third of the closed form's own
+ * rounding noise there (3e-9 m).  Rounds 1 and 2 allowed 2e-10 m; at 1e-9 m a line
+ * reaches 1.5 x as far (5^(1/4): 760 m at latitude 45) and a ray takes a third fewer
+ * closed forms (round 3, measured: C2 4.17 -> 4.05 ms, C4 30.2 -> 28.8; 3e-9 and 1e-8
+ * bring no more, the million rays of C2 against the CPU restatement the same 0 / 0,
+ * worst path length 2.1e-8 against 1.6e-8). */
+#ifndef LINE_TOLERANCE
+#define LINE_TOLERANCE 1e-9
+#endif
+#ifndef LINE_TAU0
+#define LINE_TAU0 2e-9
+#endif
+constexpr double kLineTolerance = LINE_TOLERANCE; /* see f_line_serves */
+/* what a lean step counts a clearance as, at most: with k4 <= kLineTolerance / 1.8e-21 (the
+ * equator) a sample that passes its reach test is then inside kLineRange as well */
+constexpr double kLeanClearance = 400.;
+static_assert(kLineTolerance / 1.8e-21 * kLeanClearance < kLineRange * kLineRange * kLineRange * kLineRange,
+    "a lean step's reach test must imply the line's hard limit");
 /* A ray's position is ACCUMULATED step by step, B += d * ds with the reference's
  * roundings [ref stepper.c:824, :862-863], in every phase: each step leaves B
  * up to half an ulp of 6.4e6 m per coordinate (8e-10 m) off the straight line,
@@ -280,9 +297,9 @@ constexpr double kLineTolerance = 2e-10; /* see f_line_serves */
  * (the samples of a bisection all leave from one accumulated position: the line
  * laid at the first of them that is too close to call serves the others -- ALL
  * the others (`bracketed`): it has no drift, and the last halvings of every ray
- * are within 1e-9 m of the ground, where its truncation (2e-10 m) is the closed
- * form's own noise.) */
-constexpr double kLineTau0 = 1e-9;  /* m: the truncation allowed near a boundary (2e-10 m) and
+ * are within 1e-9 m of the ground, where its truncation (kLineTolerance) is below
+ * the closed form's own noise.) */
+constexpr double kLineTau0 = LINE_TAU0;  /* m: the truncation allowed near a boundary (1e-9 m) and
                                      * the rounding of latitude and longitude (8e-10 m on the
                                      * ground, a third of that in elevation) */
 constexpr double kLineDrift = 1e-9; /* m per step: (3 x (2^-31)^2)^0.5 = 8.1e-10 rounded up */
@@ -297,10 +314,10 @@ struct RayLine {
 
 /* Is the line good enough for a sample at parameter s that came out at
  * `clearance` metres from the nearest boundary?  The truncation error must be
- * below 2e-10 m (a tenth of the closed form's own rounding noise) -- or, far
- * from any boundary, below 2e-10 OF the clearance: all such a sample decides
- * is the length of the next step, to the same relative accuracy.  At latitude
- * 45 this lets a line serve 500 m near the ground and ~2 km in free flight. */
+ * below kLineTolerance = 1e-9 m (a third of the closed form's own rounding noise)
+ * -- or, far from any boundary, below 1e-9 OF the clearance: all such a sample
+ * decides is the length of the next step, to the same relative accuracy.  At
+ * latitude 45 this lets a line serve 760 m near the ground and ~3 km in free flight. */
 __device__ __forceinline__ bool f_line_serves(const RayLine & L, double s, double clearance,
     bool bracketed = false)
 {
@@ -2212,10 +2229,10 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                          *   sgn t > tau                  => the line serves as to drift and
                          *                                   truncation near the boundary (|t| > tau)
                          *                                   AND the medium is the ray's;
-                         *   k4 min(max(|t|, 1), 2000) > s^4  => the line serves as to its reach,
+                         *   k4 min(max(|t|, 1), 400) > s^4   => the line serves as to its reach,
                          *                                   which is then below kLineRange too
-                         *                                   ((1.11e11 x 2000)^(1/4) = 3852 m at the
-                         *                                   equator, where k4 is largest);
+                         *                                   (kLeanClearance: (5.56e11 x 400)^(1/4) =
+                         *                                   3862 m at the equator, where k4 is largest);
                          * and a step within kCreepUnroll of the cap is left to the general
                          * iteration.  Two compares a step decide it where the reference's
                          * tests, one by one, took a dozen and as many scalar instructions
@@ -2263,7 +2280,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                         const double clearance = fabs(t);
                                         const double s2 = sl * sl;
                                         going = going & (__builtin_fma(sgn, t, -line.tau) > 0.) &
-                                            (__builtin_fma(line.k4, fmin(fmax(clearance, 1.), 2000.), -(s2 * s2)) > 0.);
+                                            (__builtin_fma(line.k4, fmin(fmax(clearance, 1.), kLeanClearance), -(s2 * s2)) > 0.);
                                         if (going) {
                                                 bx = d_along<FAST>(bx, dx, ds), by = d_along<FAST>(by, dy, ds), bz = d_along<FAST>(bz, dz, ds);
                                                 line.tau = line.tau + kLineDrift;
