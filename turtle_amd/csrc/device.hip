@@ -1923,7 +1923,10 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
 constexpr int kChunk = 64; /* rays a wave draws from the global queue at once */
 constexpr int kTailChunk = 8; /* ... in the last phase of a fast trace: few, and long */
 constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many live lanes */
-constexpr int kCreepUnroll = 8; /* steps per trip of the one-map creep loop */
+#ifndef CREEP_UNROLL
+#define CREEP_UNROLL 32
+#endif
+constexpr int kCreepUnroll = CREEP_UNROLL; /* steps per trip of the one-map creep loop */
 constexpr int kCreepBackoff = 8; /* general iterations a busy wave waits after a useless group */
 #ifndef TRACE_RELAY_BATCH
 #define TRACE_RELAY_BATCH 12
