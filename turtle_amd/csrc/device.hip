@@ -1927,7 +1927,10 @@ constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many l
 #define CREEP_UNROLL 32
 #endif
 constexpr int kCreepUnroll = CREEP_UNROLL; /* steps per trip of the one-map creep loop */
-constexpr int kCreepBackoff = 8; /* general iterations a busy wave waits after a useless group */
+#ifndef CREEP_BACKOFF
+#define CREEP_BACKOFF 8
+#endif
+constexpr int kCreepBackoff = CREEP_BACKOFF; /* general iterations a busy wave waits after a useless group */
 #ifndef TRACE_RELAY_BATCH
 #define TRACE_RELAY_BATCH 12
 #endif
