@@ -1997,6 +1997,14 @@ struct PhaseIO {
         int creep_lanes;     /* the creep loop engages at or below this many live lanes */
         int dense_go;        /* ... and above, while at least this many lanes step on (0: never) */
         CrossList cross;     /* CROSS: where to list the rays whose step crossed a boundary */
+        /* the sorted hand-over (phase A -> B): the list is filled from both ends -- the
+         * rays expected to go on for long from the front, the others from the back --
+         * and read front first (see where phase A parks) */
+        ull * n_parked_back;    /* A: the number of rays listed from the back (or NULL: one end) */
+        const ull * n_dev_back; /* B: the same, to read the list */
+        double * ds_mark;       /* A: a ray's step length at step mark_at */
+        int mark_at;
+        float long_if;          /* A: to the front, if expected to take more further steps than this */
 };
 
 /* CROSS: a ray whose step crossed a boundary is not bisected here (ST_BISECT
@@ -2013,7 +2021,12 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
     int flags, const PhaseIO & ph, ull * __restrict__ stats, ull * __restrict__ queue)
 {
-        if (ph.n_dev != nullptr) n = (long)*ph.n_dev;
+        const long capacity = n; /* of the lists ph.ids, ph.parked */
+        long n_front = n;
+        if (ph.n_dev != nullptr) {
+                n_front = (long)*ph.n_dev;
+                n = n_front + ((ph.n_dev_back != nullptr) ? (long)*ph.n_dev_back : 0);
+        }
         /* MODEL: besides its accumulated position B (bx, by, bz: the reference's
          * roundings, in every phase: see kLineTau0) a ray on its line carries
          * line.s, the path length from the point where the line was laid to B */
@@ -2076,7 +2089,8 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                         if (need && (rank < avail)) {
                                 ray = pool_next + rank;
-                                if (ph.ids != nullptr) ray = ph.ids[ray];
+                                if (ph.ids != nullptr)
+                                        ray = ph.ids[(ray < n_front) ? ray : capacity - 1 - (ray - n_front)];
                                 if (MODEL) line.valid = false, line.s = 0., line.tau = kLineTau0;
                                 bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
                                 dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
@@ -2512,17 +2526,48 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                         }
                 }
                 /* ---- park over-long rays (phase A; whole wave takes part) ---- */
+                if (!MODEL && (ph.ds_mark != nullptr) && (ray >= 0) && (state == ST_STEP) &&
+                    (count == ph.mark_at))
+                        ph.ds_mark[ray] = ds;
                 const ull pmask = __ballot(park);
                 if (pmask != 0) {
+                        /* Phase A sorts what it hands over.  A launch of phase B ends with
+                         * the chip all but empty, waiting for the few rays of thousands of
+                         * steps -- the later one of those was drawn from the queue, the
+                         * longer.  A ray whose steps shrank from d0 (at step mark_at) to ds
+                         * now will, at that rate, be down to the minimum step after
+                         *   ln(ds / resolution) / (ln(d0 / ds) / (count - mark_at))
+                         * more: a crude figure that tells what matters -- the rays heading
+                         * straight for the ground have little there (of C2's rays at step 32
+                         * the 40 % below 120 hold none of the 4 % that take over 500 further
+                         * steps, nor any of the 0.1 % over 2 000), and they go to the back of
+                         * the list.  Where a ray is listed changes when phase B takes it, not
+                         * what comes out. */
+                        bool back = false;
+                        if (!MODEL && (ph.n_parked_back != nullptr) && park && (count > ph.mark_at)) {
+                                const float shrink = __logf((float)ph.ds_mark[ray] / (float)ds);
+                                const float togo = __logf((float)ds / (float)v.resolution);
+                                back = (shrink > 0.f) &&
+                                    !(togo * (float)(count - ph.mark_at) > ph.long_if * shrink);
+                        }
+                        const ull bmask = __ballot(back);
+                        const ull fmask = pmask & ~bmask;
                         const int leader = __builtin_ctzll(pmask);
-                        ull base = 0;
-                        if ((int)(threadIdx.x & 63) == leader)
-                                base = atomicAdd(ph.n_parked, (ull)__popcll(pmask));
+                        ull base = 0, base_back = 0;
+                        if ((int)(threadIdx.x & 63) == leader) {
+                                if (fmask != 0) base = atomicAdd(ph.n_parked, (ull)__popcll(fmask));
+                                if (bmask != 0) base_back = atomicAdd(ph.n_parked_back, (ull)__popcll(bmask));
+                        }
                         base = __shfl(base, leader, 64);
+                        base_back = __shfl(base_back, leader, 64);
                         if (park) {
-                                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pmask >> 32),
-                                    __builtin_amdgcn_mbcnt_lo((unsigned)pmask, 0));
-                                ph.parked[base + rank] = (int)ray;
+                                const ull mine = back ? bmask : fmask;
+                                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
+                                if (back)
+                                        ph.parked[capacity - 1 - (long)(base_back + rank)] = (int)ray;
+                                else
+                                        ph.parked[base + rank] = (int)ray;
                                 pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
                                 index[2 * ray] = m, index[2 * ray + 1] = k;
                                 length[ray] = len;
@@ -3533,6 +3578,13 @@ static int dense_go(void)
         if (value < 0) value = env_int("TURTLE_AMD_DENSE_GO", 24);
         return value;
 }
+/* What phase A takes for a long ray when it sorts its hand-over (see there; 0: unsorted) */
+static int sort_long_if(void)
+{
+        static int value = -1;
+        if (value < 0) value = env_int("TURTLE_AMD_SORT_LONG", 120);
+        return value;
+}
 static int drain_lanes(void)
 {
         static int value = -1;
@@ -3564,8 +3616,9 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         if (again) flags |= TRACE_CARRY_MEDIUM;
         const int resume = again ? 2 : 0;
         const bool strict = g_math_strict || !view.fast_ok;
-        /* lists: parked[0 .. n) from A to B, parked[n .. 3n) the crossings; counters:
-         * queue[0], [1]: the work queues of A, B; queue[2], [3]: the lengths of the lists */
+        /* lists: parked[0 .. n) from A to B (from both ends), parked[n .. 3n) the crossings;
+         * counters: queue[0], [1]: the work queues of A, B; queue[2], [3]: the lengths of the
+         * lists; queue[4]: of the first list's far end */
         const bool listed = (parked != nullptr) && (cross_ds != nullptr) && (length != nullptr) &&
             (n_steps != nullptr);
         const CrossList none = { nullptr, nullptr, nullptr, nullptr };
@@ -3592,13 +3645,20 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
                         return 1;
                 return launch_cross<MODE, true>(view, n, pos, dir, index, length, n_steps, cross, pg, stats);
         }
-        const PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, resume, pg, drain_lanes(), 0,
+        PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, resume, pg, drain_lanes(), 0,
                 kChunk, creep_lanes(n), dense_go(), cross };
+        PhaseIO b = { parked, queue + 2, nullptr, nullptr, 0, 1, pg, 0, park, kChunk,
+                creep_lanes(n), dense_go(), cross };
+        const int long_if = sort_long_if();
+        if (!again && (long_if > 0)) {
+                /* (a later round of a paged trace takes rays at any step count: unsorted) */
+                a.n_parked_back = queue + 4, a.ds_mark = cross_ds + 2 * n, a.mark_at = park / 2;
+                a.long_if = (float)long_if;
+                b.n_dev_back = queue + 4;
+        }
         if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
                 n_steps, flags, a, stats, queue))
                 return 1;
-        const PhaseIO b = { parked, queue + 2, nullptr, nullptr, 0, 1, pg, 0, park, kChunk,
-                creep_lanes(n), dense_go(), cross };
         if (launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
                 n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1))
                 return 1;
@@ -3606,7 +3666,8 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
 }
 
 /* queue: five counters (see run_trace); parked: room for 3 n ray ids and cross_ds
- * for n doubles (the lists of the passes), or NULL.  pg: the round of a paged
+ * for 3 n doubles (the lists of the passes; what the hand-over sorts by in the last n),
+ * or NULL.  pg: the round of a paged
  * geometry (paging.c), all NULL otherwise; the counters in `stats` add up over the
  * rounds of a call. */
 extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,

@@ -613,9 +613,10 @@ enum turtle_return turtle_stepper_position_n(struct turtle_stepper * stepper, lo
 /* Grow-only scratch of the batch calls: 4 n ints (the rays a trace hands from
  * pass to pass, the rays whose step crossed a boundary and what they found
  * there / the rays a batch of steps defers to its bisection pass; the step
- * counts of a trace whose caller wants none) followed by 3 n doubles (the step a
+ * counts of a trace whose caller wants none) followed by 4 n doubles (the step a
  * ray that waits for a tile was about to take; the crossing steps; the path
- * lengths of a trace whose caller wants none).  0 if it holds n entries; 1 if n
+ * lengths of a trace whose caller wants none; the step lengths a trace sorts its
+ * hand-over by).  0 if it holds n entries; 1 if n
  * is beyond an int (the caller does without); parked_capacity < 0 after a device
  * failure. */
 static int tamd_stepper_scratch(struct turtle_stepper * stepper, long n)
@@ -633,7 +634,7 @@ static int tamd_stepper_scratch(struct turtle_stepper * stepper, long n)
         }
         const size_t ints = (((size_t)n * 4 * sizeof(int) + 255) / 256) * 256;
         stepper->parked_capacity = 0;
-        if (tamd_dev_malloc((void **)&stepper->d_parked, ints + (size_t)n * 3 * sizeof(double))) {
+        if (tamd_dev_malloc((void **)&stepper->d_parked, ints + (size_t)n * 4 * sizeof(double))) {
                 stepper->parked_capacity = -1;
                 return 1;
         }
