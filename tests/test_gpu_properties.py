@@ -130,6 +130,29 @@ def test_creep_loop_changes_no_bit(tmp_path):
             assert np.array_equal(r[key], ref), (which, key)
 
 
+def test_sorted_hand_over_changes_no_bit(tmp_path):
+    """Phase A lists the rays it hands over from both ends of the list -- the ones heading for the
+    ground at the back, which the lined pass reads last.  Where a ray is listed
+    changes when it is traced, not what comes out: the same bits with the list unsorted
+    (TURTLE_AMD_SORT_LONG=0), at the default, with every ray at the back and with a figure that
+    splits the batch in the middle."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    results = {}
+    for figure in ("0", "120", "1000000", "400"):
+        out = os.path.join(tmp_path, f"sort{figure}.npz")
+        env = dict(os.environ, TURTLE_AMD_SORT_LONG=figure)
+        subprocess.run([sys.executable, os.path.join(here, "creep_probe.py"), out,
+                        os.path.join(tmp_path, f"work{figure}")], check=True, env=env, timeout=300)
+        results[figure] = dict(np.load(out))
+    base = results["0"]
+    assert base["map_n_steps"].max() > 2000 and base["stack_n_steps"].max() > 2000
+    for figure, r in results.items():
+        for key, ref in base.items():
+            assert np.array_equal(r[key], ref), (figure, key)
+
+
 def test_hand_over_step_moves_no_result(tmp_path):
     """A ray goes on its line at a fixed step count (TURTLE_AMD_PARK: 32 by default for one map and
     for a stack).  That count decides which arithmetic takes which sample -- not
