@@ -318,14 +318,34 @@ def run_workload(name, args, env, headline):
     direction = TA.ecef_from_horizontal(t_lat, t_lon, t_az, t_el)
     assert int((di != 0).sum()) == 0
     del t_lat, t_lon, t_az, t_el
-    pos = torch.empty_like(pos0)
-    index = torch.empty((n, 2), dtype=torch.int32, device=dev)
-    length = torch.empty(n, dtype=torch.float64, device=dev)
-    nsteps = torch.empty(n, dtype=torch.int32, device=dev)
+    scatter = name == "c5"
+    # ---- batches in flight: a stepper, a stream and a set of arrays each (one stepper is
+    # one stream of calls, as one turtle_stepper is one thread's in the reference) ----
+    width = args.in_flight if args.in_flight > 0 else (1 if (scatter or (use_stack and args.stack_size)) else 2)
+    main_stream = torch.cuda.current_stream()
     n_media, n_bins, lmax = 2, 1024, 65536.0
     t_hits, t_hist, t_steps, t_size = sharding.tally_layout(n_media, n_bins)
-    tally = torch.zeros(t_size, dtype=torch.int64, device=dev)
-    scatter = name == "c5"
+
+    class Flight:
+        def __init__(self, k):
+            self.stepper, self.stream = stepper, main_stream
+            if k > 0:
+                self.stepper = TA.Stepper()
+                (self.stepper.add_stack if use_stack else self.stepper.add_map)(terrain.handle, 0.0)
+                self.stream = torch.cuda.Stream(device=dev)
+            self.pos = torch.empty_like(pos0)
+            self.index = torch.empty((n, 2), dtype=torch.int32, device=dev)
+            self.length = torch.empty(n, dtype=torch.float64, device=dev)
+            self.nsteps = torch.empty(n, dtype=torch.int32, device=dev)
+            self.tally = torch.zeros(t_size, dtype=torch.int64, device=dev)
+
+        def enter(self):
+            torch.cuda.set_stream(self.stream)
+            TA.set_stream(self.stream)
+
+    flights = [Flight(k) for k in range(width)]
+    pos, index, length, nsteps, tally = (flights[0].pos, flights[0].index, flights[0].length,
+                                         flights[0].nsteps, flights[0].tally)
     first_ray = rank * n
     walk_state = {}
 
@@ -335,45 +355,55 @@ def run_workload(name, args, env, headline):
         order = torch.argsort(nsteps, descending=args.sort_steps > 0, stable=True)
         pos0, direction = pos0[order].contiguous(), direction[order].contiguous()
 
-    def one_pass():
+    def one_pass(f):
         if not scatter:
-            stepper.trace_into(pos, direction, index, length, nsteps, args.max_steps)
+            f.stepper.trace_into(f.pos, direction, f.index, f.length, f.nsteps, args.max_steps)
             return
         # C5: turtle_stepper_scatter_n samples the origins, then takes scatter-steps
         # single steps per ray, each resumed from the sample of the one before,
         # directions drawn and sums kept in the kernels
-        walk_state["w"] = stepper.scatter(pos, SEED, args.scatter_steps, first_ray=first_ray)
+        walk_state["w"] = f.stepper.scatter(f.pos, SEED, args.scatter_steps, first_ray=first_ray)
 
-    def reduce_tally():
-        tally.zero_()
+    def reduce_tally(f):
+        f.tally.zero_()
         if scatter:
             w = walk_state["w"]
-            TA.tally(w["index"], w["length"], n_media, n_bins, lmax, tally[t_hits], tally[t_hist])
-            tally[t_steps] = w["steps"].sum(dtype=torch.int64)
+            TA.tally(w["index"], w["length"], n_media, n_bins, lmax, f.tally[t_hits], f.tally[t_hist])
+            f.tally[t_steps] = w["steps"].sum(dtype=torch.int64)
         else:
-            TA.tally(index, length, n_media, n_bins, lmax, tally[t_hits], tally[t_hist])
-            tally[t_steps] = nsteps.sum(dtype=torch.int64)
-        sharding.all_reduce_tally(tally, world)   # RCCL, ~8 KB: the only collective
+            TA.tally(f.index, f.length, n_media, n_bins, lmax, f.tally[t_hits], f.tally[t_hist])
+            f.tally[t_steps] = f.nsteps.sum(dtype=torch.int64)
+        sharding.all_reduce_tally(f.tally, world)   # RCCL, ~8 KB: the only collective
+
+    def passes(count, lanes, events=None):
+        for k in range(count):
+            f = lanes[k % len(lanes)]
+            f.enter()
+            f.pos.copy_(pos0)                # a pass advances positions in place
+            if events is not None:
+                events[k][0].record()        # HIP events on the launch stream
+            one_pass(f)
+            if events is not None:
+                events[k][1].record()
+            reduce_tally(f)
+        flights[0].enter()
 
     steps = args.steps if headline else 1
     warmup = args.warmup if headline else 1
-    for _ in range(warmup):
-        pos.copy_(pos0)                      # a pass advances positions in place
-        one_pass()
-        reduce_tally()
+    torch.cuda.synchronize()                 # the rays are there for every stream
+    passes(max(warmup, width), flights)      # (every stepper's scratch comes with its first pass)
+    if not headline and width > 1:
+        steps = 2 * width                    # an `also` leg with batches in flight: a few passes
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(steps)]
+    def new_events(count):
+        return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                for _ in range(count)]
+    ev = new_events(steps)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(steps):
-        pos.copy_(pos0)
-        ev[k][0].record()                    # HIP events on the launch stream
-        one_pass()
-        ev[k][1].record()
-        reduce_tally()
+    passes(steps, flights, ev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -387,6 +417,15 @@ def run_workload(name, args, env, headline):
     stats = stepper.trace_stats()            # of the last pass on this rank
     total_steps_per_pass = int(tally[t_steps].item())   # all ranks (all-reduced)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kernel_ms_in_flight = None
+    if width > 1:
+        # the kernels of ONE pass, alone on the GPU (what profiles/ hold and the roofline is
+        # about): a few passes more, one batch in flight, outside the timed region
+        kernel_ms_in_flight = kernel_ms
+        alone = new_events(max(3, min(steps, 10)))
+        passes(len(alone), flights[:1], alone)
+        torch.cuda.synchronize()
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in alone]))
     out = None
     if rank == 0:
         value = total_steps_per_pass * steps / elapsed
@@ -433,8 +472,19 @@ def run_workload(name, args, env, headline):
                                            if (use_stack and args.stack_size) else ""),
                        "rays_per_gpu": n, "max_steps": args.max_steps,
                        "slope": 0.4, "resolution": 1e-2, "math": TA.get_math(),
-                       "parallelism": f"rays x{world}"},
+                       "parallelism": f"rays x{world}", "in_flight": width},
             "kernel": kernel,
+            "in_flight": {"batches": width,
+                          "note": ("passes of one batch each, taken in turn by `batches` steppers on streams of "
+                                   "their own (one stepper is one stream of calls): a trace ends with a few "
+                                   "rays of thousands of steps, which then step beside the bulk of the next "
+                                   "batch.  `value` and `ms_per_step` are the whole timed region's; `kernel` and "
+                                   "`roofline` are one pass alone on the GPU, measured with HIP events "
+                                   + ("in the timed region itself" if width == 1 else
+                                      "right after it (under overlap a pass's own events span "
+                                      f"{kernel_ms_in_flight:.3f} ms)")),
+                          "ms_per_step_alone": kernel_ms,
+                          "value_alone": stats["steps"] * world / (kernel_ms * 1e-3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
@@ -514,6 +564,8 @@ def run_workload(name, args, env, headline):
                                               res["index"], res["length"], nsteps[:m].cpu().numpy(),
                                               res["n_steps"])
                 out["cpu_baseline"] = cpu_baseline_entry(cpu, cores, m)
+    for f in flights[1:]:
+        f.stepper.destroy()
     terrain.close()
     return out
 
@@ -544,6 +596,10 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=1_000_000,
                     help="rays of the headline's CPU-baseline sample (default: the whole C2 batch)")
     ap.add_argument("--no-cpu", action="store_true", help="no CPU baseline, no parity count")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="batches in flight: steppers on streams of their own that take the passes in "
+                         "turn, so that the few long rays a trace ends with step beside the bulk of the "
+                         "next batch (0: two for a trace over resident terrain, else one)")
     ap.add_argument("--tiles", choices=("auto", "hgt", "tif"), default="auto",
                     help="tile files: SRTM's .hgt, ASTER-GDEM2's GeoTIFF-16 (auto: tif for c5, hgt else)")
     args = ap.parse_args()
@@ -615,9 +671,9 @@ def main():
             if strict:
                 TA.set_math(os.environ.get("TURTLE_AMD_MATH", "fast"))
         if rank == 0:
-            extra[name + (f"_stack_size_{sub.stack_size}" if sub.stack_size else "") + ("_strict" if strict else "")] = {"metric": "ray-steps/s", "value": r["value"], "passes": 1,
+            extra[name + (f"_stack_size_{sub.stack_size}" if sub.stack_size else "") + ("_strict" if strict else "")] = {"metric": "ray-steps/s", "value": r["value"], "passes": r["steps"],
                            "ms_per_pass": r["ms_per_step"], "config": r["config"],
-                           "kernel": r["kernel"], "roofline": r["roofline"],
+                           "kernel": r["kernel"], "in_flight": r["in_flight"], "roofline": r["roofline"],
                            **({"parity": r["parity"]} if "parity" in r else {}),
                            **({"cpu_baseline": r["cpu_baseline"]} if "cpu_baseline" in r else {})}
 
@@ -628,8 +684,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": head["config"], "kernel": head["kernel"], "roofline": head["roofline"],
-            "tally": head["tally"],
+            "config": head["config"], "kernel": head["kernel"], "in_flight": head["in_flight"],
+            "roofline": head["roofline"], "tally": head["tally"],
         }
         for key in ("parity", "cpu_baseline"):
             if key in head:

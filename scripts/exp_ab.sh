@@ -6,7 +6,7 @@ out=gpurun_out/ab; mkdir -p $out
 i=0
 for setting in "$@"; do
   i=$((i+1))
-  ( export $setting; timeout -k 10 300 python3 bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu --workload ${WL:-c2} --rays ${RAYS:-0} > $out/log_$i.txt 2>&1 )
+  ( export $setting; timeout -k 10 300 python3 bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu --in-flight 1 --workload ${WL:-c2} --rays ${RAYS:-0} > $out/log_$i.txt 2>&1 )
   echo "== $setting (exit $?)"
   python3 - $out/log_$i.txt <<'PY'
 import json, sys

@@ -6,7 +6,7 @@ wl=${1:-c4}; [ -n "$2" ] && export $2
 out=gpurun_out/flow_pmc; rm -rf $out; mkdir -p $out
 run() { name=$1; shift
   timeout -k 10 400 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_$name -- \
-      python3 bench.py --workload $wl --also none --steps 2 --warmup 1 --no-cpu > $out/pmc_$name.log 2>&1; echo "pmc $name exit $?"; }
+      python3 bench.py --workload $wl --also none --steps 2 --warmup 1 --no-cpu --in-flight 1 > $out/pmc_$name.log 2>&1; echo "pmc $name exit $?"; }
 run A SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 run B SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA
 python3 - $out <<'PY'

@@ -8,7 +8,7 @@ for setting in "$@"; do
   i=$((i+1))
   ( export $setting
     timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/t$i -- \
-      python3 bench.py --workload ${WL:-c2} --also none --no-cpu --steps 4 --warmup 1 > $out/log_$i.txt 2>&1 )
+      python3 bench.py --workload ${WL:-c2} --also none --no-cpu --in-flight 1 --steps 4 --warmup 1 > $out/log_$i.txt 2>&1 )
   echo "== $setting (exit $?)"
   python3 scripts/trace_timeline.py $out/t$i "k_trace|k_cross|k_flow" | tail -${TL:-6}
   rm -rf $out/t$i

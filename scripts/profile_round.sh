@@ -8,7 +8,7 @@ tag=${1:-rXX}
 wl=${2:-c2}
 rays=${3:-0}
 passes=${4:-A B C D}
-WL="--workload $wl --rays $rays --also none"
+WL="--workload $wl --rays $rays --also none --in-flight 1"   # one batch at a time: the kernels alone on the GPU
 kernel="k_trace|k_cross"; [ "$wl" = c5 ] && kernel=k_walk
 out=gpurun_out/$tag
 mkdir -p $out

@@ -28,7 +28,7 @@ def c2(tmp_path_factory):
     pos, di = st.position(lat, lon, 500.0)
     assert (di == 0).all()
     d = TA.ecef_from_horizontal(lat, lon, az, el)
-    yield dict(stepper=st, pos=pos, dir=d)
+    yield dict(stepper=st, pos=pos, dir=d, map=tile)
     st.destroy()
     tile.destroy()
 
@@ -128,6 +128,43 @@ def test_creep_loop_changes_no_bit(tmp_path):
     for which, r in results.items():
         for key, ref in base.items():
             assert np.array_equal(r[key], ref), (which, key)
+
+
+def test_two_batches_in_flight_give_the_same_bits(c2):
+    """One stepper is one stream of calls (as one turtle_stepper is one thread's in the
+    reference); two of them over the same map, each on a stream of its own, take batches in
+    turn -- the few long rays a trace ends with then step beside the bulk of the next batch
+    (bench.py's `in_flight`).  Same bits as one after the other, and as the fixture's stepper."""
+    import torch
+    dev = torch.device("cuda", 0)
+    pos0 = torch.as_tensor(c2["pos"], device=dev)
+    d = torch.as_tensor(c2["dir"], device=dev)
+    ref = c2["stepper"].trace(c2["pos"].copy(), c2["dir"])
+    steppers, streams = [], []
+    try:
+        for _ in range(2):
+            st = TA.Stepper()
+            st.add_map(c2["map"], 0.0)
+            steppers.append(st)
+            streams.append(torch.cuda.Stream(device=dev))
+        torch.cuda.synchronize()
+        outs = [None, None]
+        bufs = [pos0.clone(), pos0.clone()]
+        for k in range(6):                    # batches 0 .. 5, two in flight at any time
+            w = k % 2
+            torch.cuda.set_stream(streams[w])
+            TA.set_stream(streams[w])
+            bufs[w].copy_(pos0)
+            outs[w] = steppers[w].trace(bufs[w], d)
+        torch.cuda.synchronize()
+        for out in outs:
+            for key in ("index", "length", "n_steps", "position"):
+                assert np.array_equal(out[key].cpu().numpy(), ref[key]), key
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        TA.set_stream(None)
+        for st in steppers:
+            st.destroy()
 
 
 def test_sorted_hand_over_changes_no_bit(tmp_path):
