@@ -321,7 +321,7 @@ def run_workload(name, args, env, headline):
     scatter = name == "c5"
     # ---- batches in flight: a stepper, a stream and a set of arrays each (one stepper is
     # one stream of calls, as one turtle_stepper is one thread's in the reference) ----
-    width = args.in_flight if args.in_flight > 0 else (1 if (scatter or (use_stack and args.stack_size)) else 2)
+    width = args.in_flight if args.in_flight > 0 else (1 if (scatter or (use_stack and args.stack_size)) else 3)
     main_stream = torch.cuda.current_stream()
     n_media, n_bins, lmax = 2, 1024, 65536.0
     t_hits, t_hist, t_steps, t_size = sharding.tally_layout(n_media, n_bins)
@@ -599,7 +599,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="batches in flight: steppers on streams of their own that take the passes in "
                          "turn, so that the few long rays a trace ends with step beside the bulk of the "
-                         "next batch (0: two for a trace over resident terrain, else one)")
+                         "next batch (0: three for a trace over resident terrain, else one)")
     ap.add_argument("--tiles", choices=("auto", "hgt", "tif"), default="auto",
                     help="tile files: SRTM's .hgt, ASTER-GDEM2's GeoTIFF-16 (auto: tif for c5, hgt else)")
     args = ap.parse_args()

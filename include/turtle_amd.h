@@ -278,8 +278,8 @@ TURTLE_API void turtle_amd_thread_release(void);
  * keep several batches IN FLIGHT: a stepper and a stream per batch (turtle_amd_stream_set
  * before each call; the steppers may share their maps and stacks).  A trace ends with
  * a few rays of thousands of steps in an all but empty GPU, which another stream's
- * batch fills: two C2 batches in flight take 2.6-2.7 ms each, one at a time 3.5 ms,
- * the same bits (bench.py `in_flight`; tests/test_gpu_properties.py). */
+ * batch fills: C2 batches take 2.65 ms each with two in flight, 2.38 with three, 3.6 ms
+ * one at a time, the same bits (bench.py `in_flight`; tests/test_gpu_properties.py). */
 TURTLE_API enum turtle_return turtle_amd_stream_set(void * hip_stream);
 TURTLE_API enum turtle_return turtle_amd_synchronize(void);
 /* Number of compute units of the selected device (0 if none). */
