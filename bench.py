@@ -484,7 +484,9 @@ def run_workload(name, args, env, headline):
                                       "right after it (under overlap a pass's own events span "
                                       f"{kernel_ms_in_flight:.3f} ms)")),
                           "ms_per_step_alone": kernel_ms,
-                          "value_alone": stats["steps"] * world / (kernel_ms * 1e-3)},
+                          "value_alone": stats["steps"] * world / (kernel_ms * 1e-3),
+                          "algorithmic_gbs": alg_bytes * steps / elapsed / 1e9,
+                          "algorithmic_frac_of_hbm": alg_bytes * steps / elapsed / 1e9 / HBM_PEAK_GBS},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
