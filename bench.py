@@ -362,12 +362,12 @@ def run_workload(name, args, env, headline):
         # C5: turtle_stepper_scatter_n samples the origins, then takes scatter-steps
         # single steps per ray, each resumed from the sample of the one before,
         # directions drawn and sums kept in the kernels
-        walk_state["w"] = f.stepper.scatter(f.pos, SEED, args.scatter_steps, first_ray=first_ray)
+        f.walk = walk_state["w"] = f.stepper.scatter(f.pos, SEED, args.scatter_steps, first_ray=first_ray)
 
     def reduce_tally(f):
         f.tally.zero_()
         if scatter:
-            w = walk_state["w"]
+            w = f.walk
             TA.tally(w["index"], w["length"], n_media, n_bins, lmax, f.tally[t_hits], f.tally[t_hist])
             f.tally[t_steps] = w["steps"].sum(dtype=torch.int64)
         else:
