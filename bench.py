@@ -330,8 +330,7 @@ def run_workload(name, args, env, headline):
         def __init__(self, k):
             self.stepper, self.stream = stepper, main_stream
             if k > 0:
-                self.stepper = TA.Stepper()
-                (self.stepper.add_stack if use_stack else self.stepper.add_map)(terrain.handle, 0.0)
+                self.stepper = stepper.clone()
                 self.stream = torch.cuda.Stream(device=dev)
             self.pos = torch.empty_like(pos0)
             self.index = torch.empty((n, 2), dtype=torch.int32, device=dev)

@@ -281,6 +281,11 @@ TURTLE_API void turtle_amd_thread_release(void);
  * batch fills: C2 batches take 2.65 ms each with two in flight, 2.38 with three, 3.6 ms
  * one at a time, the same bits (bench.py `in_flight`; tests/test_gpu_properties.py). */
 TURTLE_API enum turtle_return turtle_amd_stream_set(void * hip_stream);
+/* A second stepper over the same geometry -- the layers and their data in the order
+ * they were added, the geoid, range, slope and resolution -- for a batch more in flight.
+ * It borrows the same maps and stacks; destroy it with turtle_stepper_destroy. */
+TURTLE_API enum turtle_return turtle_amd_stepper_clone(
+    const struct turtle_stepper * stepper, struct turtle_stepper ** clone);
 TURTLE_API enum turtle_return turtle_amd_synchronize(void);
 /* Number of compute units of the selected device (0 if none). */
 TURTLE_API int turtle_amd_compute_units(void);

@@ -142,9 +142,12 @@ def test_two_batches_in_flight_give_the_same_bits(c2):
     ref = c2["stepper"].trace(c2["pos"].copy(), c2["dir"])
     steppers, streams = [], []
     try:
-        for _ in range(2):
-            st = TA.Stepper()
-            st.add_map(c2["map"], 0.0)
+        for k in range(2):
+            if k == 0:
+                st = TA.Stepper()
+                st.add_map(c2["map"], 0.0)
+            else:
+                st = c2["stepper"].clone()      # turtle_amd_stepper_clone
             steppers.append(st)
             streams.append(torch.cuda.Stream(device=dev))
         torch.cuda.synchronize()

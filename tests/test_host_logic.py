@@ -226,6 +226,35 @@ def test_stepper_layer_rules():
     m.destroy()
 
 
+@pytest.mark.skipif(HAS_GPU, reason="uses the no-device failure to stop before compute")
+def test_stepper_clone():
+    """turtle_amd_stepper_clone: the layers as they were added, the geoid and the settings; the
+    clone borrows the same data and is destroyed on its own."""
+    m, g = TA.Map.create(shape=(2, 2)), TA.Map.create(shape=(2, 2))
+    st = TA.Stepper()
+    st.add_flat(-1.0)
+    st.add_layer()
+    st.add_map(m, 1.0)
+    st.add_map(m, 2.0)
+    st.geoid_set(g)
+    st.range, st.slope, st.resolution = 0.0, 0.5, 1e-3
+    c = st.clone()
+    assert (c.range, c.slope, c.resolution) == (0.0, 0.5, 1e-3)
+    assert TA.lib().turtle_stepper_geoid_get(c.h) == g.h.value
+    assert _layer_exists(c, 0) and _layer_exists(c, 1) and not _layer_exists(c, 2)
+    c.add_layer()
+    c.add_flat(5.0)                      # the clone grows on its own
+    assert _layer_exists(c, 2) and not _layer_exists(st, 2)
+    c.destroy()
+    assert _layer_exists(st, 1) and st.slope == 0.5
+    empty = TA.Stepper().clone()         # nothing added yet: nothing to copy
+    assert not _layer_exists(empty, 0)
+    empty.destroy()
+    st.destroy()
+    m.destroy()
+    g.destroy()
+
+
 def test_projection_names():
     """The name parser [ref projection.c:98-171], quirks included."""
     for name in ("Lambert I", "Lambert II", "Lambert IIe", "Lambert III", "Lambert IV",

@@ -449,6 +449,15 @@ class Stepper:
         self._keep = []
         _check(lib().turtle_stepper_create(C.byref(self.h)))
 
+    def clone(self):
+        """A second stepper over the same geometry and settings (turtle_amd_stepper_clone): one
+        stepper is one stream of calls, a batch more in flight takes a stepper more."""
+        other = Stepper.__new__(Stepper)
+        other.h = C.c_void_p()
+        other._keep = list(self._keep)
+        _check(lib().turtle_amd_stepper_clone(self.h, C.byref(other.h)))
+        return other
+
     def add_layer(self):
         _check(lib().turtle_stepper_add_layer(self.h))
 

@@ -120,6 +120,7 @@ const char * turtle_error_function(turtle_function_t * caller)
         NAME(turtle_amd_isotropic_n);
         NAME(turtle_amd_device_set);
         NAME(turtle_amd_stream_set);
+        NAME(turtle_amd_stepper_clone);
         NAME(turtle_amd_synchronize);
         return NULL;
 #undef NAME

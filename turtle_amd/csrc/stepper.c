@@ -195,6 +195,46 @@ enum turtle_return turtle_stepper_add_flat(struct turtle_stepper * stepper, doub
         return TURTLE_RETURN_SUCCESS;
 }
 
+/* A second stepper over the same geometry: the layers and their data in the order they
+ * were added, the geoid and the settings (turtle_amd.h: one stepper is one stream of
+ * calls; a batch more in flight takes a stepper more).  Built with the public calls, so
+ * that it is exactly what the caller's own sequence of them would have made. */
+enum turtle_return turtle_amd_stepper_clone(
+    const struct turtle_stepper * stepper, struct turtle_stepper ** clone)
+{
+        TAMD_ERROR_INIT(&turtle_amd_stepper_clone);
+        if ((stepper == NULL) || (clone == NULL))
+                return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "a stepper and where to put its clone");
+        *clone = NULL;
+        struct turtle_stepper * c = NULL;
+        enum turtle_return rc = turtle_stepper_create(&c);
+        int i, j;
+        for (i = 0; (rc == TURTLE_RETURN_SUCCESS) && (i < stepper->n_layers); i++) {
+                /* (an empty layer is one more add_layer: push_layer reuses an empty top layer) */
+                rc = turtle_stepper_add_layer(c);
+                for (j = 0; (rc == TURTLE_RETURN_SUCCESS) && (j < stepper->layers[i].size); j++) {
+                        const struct tamd_layer_meta * m = &stepper->layers[i].meta[j];
+                        const struct tamd_data * d = &stepper->data[m->data];
+                        if (d->kind == TAMD_MAP)
+                                rc = turtle_stepper_add_map(c, d->map, m->offset);
+                        else if (d->kind == TAMD_STACK)
+                                rc = turtle_stepper_add_stack(c, d->stack, m->offset);
+                        else
+                                rc = turtle_stepper_add_flat(c, m->offset);
+                }
+        }
+        if (rc != TURTLE_RETURN_SUCCESS) {
+                turtle_stepper_destroy(&c);
+                return rc;
+        }
+        c->geoid = stepper->geoid;
+        c->local_range = stepper->local_range;
+        c->slope_factor = stepper->slope_factor;
+        c->resolution_factor = stepper->resolution_factor;
+        *clone = c;
+        return TURTLE_RETURN_SUCCESS;
+}
+
 /* ---- setters/getters [ref stepper.c:617-672] ----------------------------- */
 
 void turtle_stepper_geoid_set(struct turtle_stepper * stepper, struct turtle_map * geoid)
