@@ -278,7 +278,7 @@ TURTLE_API void turtle_amd_thread_release(void);
  * keep several batches IN FLIGHT: a stepper and a stream per batch (turtle_amd_stream_set
  * before each call; the steppers may share their maps and stacks).  A trace ends with
  * a few rays of thousands of steps in an all but empty GPU, which another stream's
- * batch fills: C2 batches take 2.65 ms each with two in flight, 2.38 with three, 3.6 ms
+ * batch fills: C2 batches take 2.6 ms each with two in flight, 2.2-2.3 with three, 3.6 ms
  * one at a time, the same bits (bench.py `in_flight`; tests/test_gpu_properties.py). */
 TURTLE_API enum turtle_return turtle_amd_stream_set(void * hip_stream);
 /* A second stepper over the same geometry -- the layers and their data in the order
@@ -286,6 +286,12 @@ TURTLE_API enum turtle_return turtle_amd_stream_set(void * hip_stream);
  * It borrows the same maps and stacks; destroy it with turtle_stepper_destroy. */
 TURTLE_API enum turtle_return turtle_amd_stepper_clone(
     const struct turtle_stepper * stepper, struct turtle_stepper ** clone);
+/* A hint, per thread: how many batches the caller keeps in flight (default 1).  With two or
+ * more a trace kernel takes a smaller share of every compute unit, which leaves room for a
+ * wave of another batch's kernel beside its own: better for the batches together, worse for
+ * one alone.  Results do not depend on it. */
+TURTLE_API void turtle_amd_in_flight_set(int batches);
+TURTLE_API int turtle_amd_in_flight_get(void);
 TURTLE_API enum turtle_return turtle_amd_synchronize(void);
 /* Number of compute units of the selected device (0 if none). */
 TURTLE_API int turtle_amd_compute_units(void);

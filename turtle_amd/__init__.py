@@ -11,6 +11,6 @@ from . import synth  # noqa: F401
 from .binding import (  # noqa: F401
     DEVICE, HOST, STEP_RESUME, Map, Projection, Stack, Stepper, TurtleError, build, device_count,
     compute_units, ecef_from_geodetic, ecef_from_horizontal, ecef_to_geodetic,
-    ecef_to_horizontal, get_math, isotropic, lib, philox, library_path, set_math, set_scalar, get_scalar, set_stream, synchronize,
+    ecef_to_horizontal, get_math, isotropic, lib, philox, library_path, set_math, set_scalar, get_scalar, set_stream, set_in_flight, get_in_flight, synchronize,
     tally,
 )

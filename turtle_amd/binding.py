@@ -167,6 +167,15 @@ def set_stream(stream=None):
     _check(lib().turtle_amd_stream_set(handle))
 
 
+def set_in_flight(batches):
+    """Hint: the batches this thread keeps in flight (turtle_amd_in_flight_set)."""
+    lib().turtle_amd_in_flight_set(int(batches))
+
+
+def get_in_flight():
+    return int(lib().turtle_amd_in_flight_get())
+
+
 def synchronize():
     _check(lib().turtle_amd_synchronize())
 

@@ -35,6 +35,10 @@ enum turtle_return turtle_amd_synchronize(void)
 
 int turtle_amd_compute_units(void) { return tamd_dev_cus(); }
 
+void turtle_amd_in_flight_set(int batches) { tamd_dev_in_flight_set(batches); }
+
+int turtle_amd_in_flight_get(void) { return tamd_dev_in_flight_get(); }
+
 void turtle_amd_math_set(int mode) { tamd_dev_math_set(mode == TURTLE_AMD_MATH_STRICT); }
 
 int turtle_amd_math_get(void)

@@ -2985,6 +2985,7 @@ struct Ctx {
         int device = -1, cus = 0;
         hipStream_t own_stream = nullptr, stream = nullptr;
         int math_strict = 0;
+        int in_flight = 1; /* batches the thread keeps in flight (tamd_dev_in_flight_set) */
         void * scratch = nullptr;
         size_t scratch_size = 0, scratch_used = 0;
         void * block[2] = { nullptr, nullptr }; /* grow-only: the pager's lists, a stack's own tables */
@@ -3448,6 +3449,20 @@ static int trace_blocks_per_cu(const void * kernel)
                 hipSuccess ||
             blocks < 1)
                 blocks = 1;
+        /* batches in flight share the SIMDs: a kernel that takes one block a CU fewer than fit
+         * leaves registers for a wave of another batch's kernel beside its own (three C2 batches
+         * in flight: 2.38 -> 2.29 ms a pass over 10 passes, 2.39 -> 2.18 over 20; C4 25.5 -> 24.7;
+         * through a stack no change -- two blocks a CU whatever fits: C2 the same, C4 24.1, but C3
+         * 23.9 -> 25.3; alone a kernel would lose either way: C2 3.55 -> 3.7 with two) */
+        if ((g_ctx.in_flight > 1) && (blocks > 2)) {
+                static int share = -1; /* experiments: 0: as many as fit, 1: one fewer, 2: two */
+                if (share < 0) {
+                        const char * e = getenv("TURTLE_AMD_IN_FLIGHT_SHARE");
+                        share = ((e != nullptr) && (*e != 0)) ? atoi(e) : 1;
+                }
+                if (share == 1) blocks -= 1;
+                if (share == 2) blocks = 2;
+        }
         const char * env = getenv("TURTLE_AMD_TRACE_WAVES");
         if ((env != nullptr) && (*env != 0)) {
                 const int waves = atoi(env); /* per SIMD == blocks of 256 per CU */
@@ -3457,6 +3472,8 @@ static int trace_blocks_per_cu(const void * kernel)
 }
 
 extern "C" void tamd_dev_math_set(int strict) { g_ctx.math_strict = strict ? 1 : 0; }
+extern "C" void tamd_dev_in_flight_set(int batches) { g_ctx.in_flight = (batches > 1) ? batches : 1; }
+extern "C" int tamd_dev_in_flight_get(void) { return g_ctx.in_flight; }
 extern "C" int tamd_dev_math_get(void) { return g_ctx.math_strict; }
 
 template <int MODE, bool FAST, bool MODEL, bool PAGED, bool CROSS>

@@ -140,6 +140,8 @@ int tamd_dev_stream_set(void * stream);
 int tamd_dev_sync(void);
 void tamd_dev_math_set(int strict); /* 1: reference-order arithmetic in k_trace */
 int tamd_dev_math_get(void);
+void tamd_dev_in_flight_set(int batches); /* the batches the thread keeps in flight (a hint: device.hip) */
+int tamd_dev_in_flight_get(void);
 
 int tamd_dev_malloc(void ** ptr, size_t bytes);
 void tamd_dev_free(void * ptr);
