@@ -151,6 +151,8 @@ def test_two_batches_in_flight_give_the_same_bits(c2):
             steppers.append(st)
             streams.append(torch.cuda.Stream(device=dev))
         torch.cuda.synchronize()
+        TA.set_in_flight(2)                   # the hint (a kernel's share of a CU): no result depends on it
+        assert TA.get_in_flight() == 2
         outs = [None, None]
         bufs = [pos0.clone(), pos0.clone()]
         for k in range(6):                    # batches 0 .. 5, two in flight at any time
@@ -164,6 +166,7 @@ def test_two_batches_in_flight_give_the_same_bits(c2):
             for key in ("index", "length", "n_steps", "position"):
                 assert np.array_equal(out[key].cpu().numpy(), ref[key]), key
     finally:
+        TA.set_in_flight(1)
         torch.cuda.set_stream(torch.cuda.default_stream(dev))
         TA.set_stream(None)
         for st in steppers:

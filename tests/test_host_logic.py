@@ -187,6 +187,14 @@ def test_stack_lock_consistency_and_client(tmp_path):
     locked.destroy()
 
 
+def test_in_flight_hint():
+    assert TA.get_in_flight() == 1
+    TA.set_in_flight(3)
+    assert TA.get_in_flight() == 3
+    TA.set_in_flight(0)                  # (anything below two is one)
+    assert TA.get_in_flight() == 1
+
+
 def test_stepper_defaults_and_setters():
     st = TA.Stepper()
     assert st.range == 1.0 and st.slope == 0.4 and st.resolution == 1e-2
