@@ -392,7 +392,7 @@ def run_workload(name, args, env, headline):
     torch.cuda.synchronize()                 # the rays are there for every stream
     passes(max(warmup, width), flights)      # (every stepper's scratch comes with its first pass)
     if not headline and width > 1:
-        steps = 2 * width                    # an `also` leg with batches in flight: a few passes
+        steps = 3 * width                    # an `also` leg with batches in flight: a few passes
 
     def new_events(count):
         return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
