@@ -576,8 +576,8 @@ def run_workload(name, args, env, headline):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None,
                     help="default: c2 as the headline, c3 and c5 once each under 'also'")
     ap.add_argument("--also", default=None,
