@@ -1921,6 +1921,10 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
 /* ---- the hot kernel ---------------------------------------------------- */
 
 constexpr int kChunk = 64; /* rays a wave draws from the global queue at once */
+#ifndef PAGED_REFILL
+#define PAGED_REFILL 24
+#endif
+constexpr int kPagedRefill = PAGED_REFILL; /* over paged tiles: the free lanes a wave waits for before it takes new rays */
 constexpr int kTailChunk = 8; /* ... in the last phase of a fast trace: few, and long */
 constexpr int kCreepLanes = 8; /* the creep loop engages at or below this many live lanes */
 #ifndef CREEP_UNROLL
@@ -2066,6 +2070,16 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                         const bool need = (ray < 0) && !dead;
                         const ull mask = __ballot(need);
                         if (mask == 0) break;
+                        /* Over paged tiles a new ray may need one that is not resident: its first
+                         * sample then takes the exact lookup, with its dependent loads, and the
+                         * ray leaves for the list -- a trip that costs the whole wave six times a
+                         * plain one.  With half the tiles away half of the new rays do, and if a
+                         * wave took new rays whenever a lane was free EVERY trip of it would be
+                         * such a one (C3 with 8 of 16 tiles: the closed-form pass 28 ms for
+                         * 6.4): the free lanes wait until there are kPagedRefill of them. */
+                        if (CAN_FAULT && (ph.pg.faulted != nullptr) && !exhausted &&
+                            (__popcll(mask) < kPagedRefill) && (__ballot(ray >= 0) != 0))
+                                break;
                         if (pool_next >= pool_end) {
                                 if (exhausted) {
                                         if (need) dead = true;
