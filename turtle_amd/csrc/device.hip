@@ -1413,11 +1413,11 @@ __device__ __forceinline__ void page_fault(const Paging & pg, const TileFault & 
                 for (int b = 0; b < 9; b++) {
                         if (!((f.mask >> b) & 1)) continue;
                         const int t = f.centre + (b / 3 - 1) * f.stride + (b % 3 - 1);
-                        atomicAdd(&pg.wanted[t], 1u);
+                        atomicAdd(&pg.wanted[(size_t)t * TAMD_DEMAND_STRIDE], 1u);
                         if (first) atomicOr(&pg.wanted_first[t >> 5], 1u << (t & 31));
                 }
                 if (also >= 0) {
-                        atomicAdd(&pg.wanted[also], 1u);
+                        atomicAdd(&pg.wanted[(size_t)also * TAMD_DEMAND_STRIDE], 1u);
                         if (first) atomicOr(&pg.wanted_first[also >> 5], 1u << (also & 31));
                 }
         }

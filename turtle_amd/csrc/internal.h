@@ -165,12 +165,18 @@ int tamd_scratch_get(void ** ptr, size_t bytes);
  * run (ids / n_in, NULL for all of 0 .. n-1) and where to list the ones that
  * met a tile that is not resident (faulted / n_faulted) and, over the tile
  * table, how much each tile is wanted.  All NULL: nothing is paged. */
+/* The demand counters of the tiles are a line apart: a batch whose rays start over tiles
+ * that are not resident adds to a handful of them millions of times in one pass, and in
+ * one line those additions queue in ONE channel of the L2 -- behind them, the loads of
+ * every other wave that go through that channel. */
+#define TAMD_DEMAND_STRIDE 32
 struct tamd_paging {
         const int * ids;
         const unsigned long long * n_in;
         int * faulted;
         unsigned long long * n_faulted;
-        unsigned * wanted;       /* per entry of the tile table: how many listed items want it */
+        unsigned * wanted;       /* per entry of the tile table: how many listed items want it
+                                  * (entry t at wanted[t * TAMD_DEMAND_STRIDE]: a cache line each) */
         unsigned * wanted_first; /* bitmap: wanted by the first item of the list (served without fail) */
         double * tentative;      /* traces: per ray, the step a waiting ray was about to take */
         int first_id;            /* the item whose wants go to wanted_first (-1: the first listed) */

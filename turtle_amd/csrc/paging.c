@@ -28,7 +28,7 @@ int tamd_pager_begin(struct tamd_pager * pager, long n, int table_entries)
         if (n < 1) n = 1;
         const size_t list = (((size_t)n * sizeof(int) + 255) / 256) * 256;
         /* demand counters (one per tile-table entry), then the bitmap of the first item */
-        const size_t counters = ((((size_t)table_entries + 1) * sizeof(unsigned) + 255) / 256) * 256;
+        const size_t counters = ((((size_t)table_entries + 1) * TAMD_DEMAND_STRIDE * sizeof(unsigned) + 255) / 256) * 256;
         const size_t bitmap = ((((size_t)table_entries + 31) / 32 + 1) * sizeof(unsigned) + 255) / 256 * 256;
         const size_t bytes = 2 * list + 256 + counters + bitmap;
         void * block;

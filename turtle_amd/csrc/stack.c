@@ -453,7 +453,7 @@ static int stack_page_in(struct turtle_stack * s, const unsigned * wanted,
         const int n = s->latitude_n * s->longitude_n, budget = tamd_stack_budget(s);
         int i, loaded = 0;
 #define FIRST(i) ((wanted_first[((i) + first_bit) >> 5] >> (((i) + first_bit) & 31)) & 1u)
-#define DEMAND(i) (wanted[(i) + first_bit])
+#define DEMAND(i) (wanted[(size_t)((i) + first_bit) * TAMD_DEMAND_STRIDE])
         /* the resident tiles this round wanted are the most recently used; the ones this
          * thread brought in last time have had their round */
         for (i = 0; i < n; i++) {
