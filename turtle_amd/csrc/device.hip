@@ -1413,13 +1413,25 @@ __device__ __forceinline__ void page_fault(const Paging & pg, const TileFault & 
                 for (int b = 0; b < 9; b++) {
                         if (!((f.mask >> b) & 1)) continue;
                         const int t = f.centre + (b / 3 - 1) * f.stride + (b % 3 - 1);
-                        atomicAdd(&pg.wanted[(size_t)t * TAMD_DEMAND_STRIDE], 1u);
+                        if (b != 4) atomicAdd(&pg.wanted[(size_t)t * TAMD_DEMAND_STRIDE], 1u); /* (the centre: below) */
                         if (first) atomicOr(&pg.wanted_first[t >> 5], 1u << (t & 31));
                 }
                 if (also >= 0) {
                         atomicAdd(&pg.wanted[(size_t)also * TAMD_DEMAND_STRIDE], 1u);
                         if (first) atomicOr(&pg.wanted_first[also >> 5], 1u << (also & 31));
                 }
+        }
+        /* the tile an item is IN: one addition per wave and tile (the rays of a batch that start
+         * over tiles not resident fault together, a wave at a time, on a handful of tiles) */
+        const bool centre = fault && (((f.mask >> 4) & 1) != 0);
+        ull left = __ballot(centre);
+        while (left != 0) {
+                const int lead = __builtin_ctzll(left);
+                const int t0 = __shfl(f.centre, lead, 64);
+                const ull same = __ballot(centre && (f.centre == t0));
+                if ((int)(threadIdx.x & 63) == lead)
+                        atomicAdd(&pg.wanted[(size_t)t0 * TAMD_DEMAND_STRIDE], (unsigned)__popcll(same));
+                left &= ~same;
         }
 }
 
