@@ -3650,6 +3650,7 @@ static int drain_lanes(void)
  * 6.9-7.8 ms against 6.0 ms.)
  * Without scratch for the lists (`parked` NULL: a batch beyond 2^31 rays) there
  * is one pass, which bisects in place. */
+constexpr int kQ = 16; /* words between two counters of a trace: see run_trace */
 template <int MODE>
 static int run_trace(struct tamd_view view, long n, double * pos, const double * dir,
     int max_steps, int * index, double * length, int * n_steps, int flags, int * parked,
@@ -3660,12 +3661,13 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         const int resume = again ? 2 : 0;
         const bool strict = g_math_strict || !view.fast_ok;
         /* lists: parked[0 .. n) from A to B (from both ends), parked[n .. 3n) the crossings;
-         * counters: queue[0], [1]: the work queues of A, B; queue[2], [3]: the lengths of the
-         * lists; queue[4]: of the first list's far end */
+         * counters, kQ words (a cache line or two) apart -- every wave of a pass adds to them:
+         * queue[0], [kQ]: the work queues of A, B; queue[2 kQ], [3 kQ]: the lengths of the lists;
+         * queue[4 kQ]: of the first list's far end */
         const bool listed = (parked != nullptr) && (cross_ds != nullptr) && (length != nullptr) &&
             (n_steps != nullptr);
         const CrossList none = { nullptr, nullptr, nullptr, nullptr };
-        const CrossList cross = { parked + n, cross_ds, queue + 3, parked + 2 * n };
+        const CrossList cross = { parked + n, cross_ds, queue + 3 * kQ, parked + 2 * n };
         const PhaseIO one = { pg.ids, pg.n_in, nullptr, nullptr, 0, resume, pg, 0, 0, kChunk,
                 creep_lanes(n), dense_go(), listed ? cross : none };
         if (!listed) {
@@ -3688,22 +3690,22 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
                         return 1;
                 return launch_cross<MODE, true>(view, n, pos, dir, index, length, n_steps, cross, pg, stats);
         }
-        PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2, park, resume, pg, drain_lanes(), 0,
+        PhaseIO a = { pg.ids, pg.n_in, parked, queue + 2 * kQ, park, resume, pg, drain_lanes(), 0,
                 kChunk, creep_lanes(n), dense_go(), cross };
-        PhaseIO b = { parked, queue + 2, nullptr, nullptr, 0, 1, pg, 0, park, kChunk,
+        PhaseIO b = { parked, queue + 2 * kQ, nullptr, nullptr, 0, 1, pg, 0, park, kChunk,
                 creep_lanes(n), dense_go(), cross };
         const int long_if = sort_long_if();
         if (!again && (long_if > 0)) {
                 /* (a later round of a paged trace takes rays at any step count: unsorted) */
-                a.n_parked_back = queue + 4, a.ds_mark = cross_ds + 2 * n, a.mark_at = park / 2;
+                a.n_parked_back = queue + 4 * kQ, a.ds_mark = cross_ds + 2 * n, a.mark_at = park / 2;
                 a.long_if = (float)long_if;
-                b.n_dev_back = queue + 4;
+                b.n_dev_back = queue + 4 * kQ;
         }
         if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
                 n_steps, flags, a, stats, queue))
                 return 1;
         if (launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
-                n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1))
+                n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1 * kQ))
                 return 1;
         return launch_cross<MODE, true>(view, n, pos, dir, index, length, n_steps, cross, pg, stats);
 }
@@ -3729,7 +3731,7 @@ extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
                 return 1;
         }
         if (pg.ids == nullptr) HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
-        HIP_TRY(hipMemsetAsync(queue, 0, 5 * sizeof(ull), g_stream));
+        HIP_TRY(hipMemsetAsync(queue, 0, 5 * kQ * sizeof(ull), g_stream));
         if (n <= 0) return 0;
         const int carry = (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0;
         if (view.mode == TAMD_MODE_ONE_MAP)

@@ -212,7 +212,7 @@ int tamd_k_step(struct tamd_view view, long n, double * pos,
  * from pass to pass (the long rays; the rays that crossed a boundary, for
  * k_cross), or NULL for a single-pass launch that bisects in place; with them,
  * length and n_steps must not be NULL. */
-#define TAMD_TRACE_COUNTERS 24
+#define TAMD_TRACE_COUNTERS 96
 int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length,
     int * n_steps, int flags, int * parked, double * cross_ds, struct tamd_paging pg,
