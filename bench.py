@@ -21,7 +21,13 @@ data-path collective; the per-step tally (hit counts + 1024-bin path-length
 histogram, uint64) is all-reduced.  Weak scaling: per-GPU work is fixed.
 --workload c4 is BASELINE configs[3]: 12.5 M rays per GPU (100 M on 8).
 
-Prints ONE JSON line on rank 0.
+Output (rank 0): one full JSON record per workload as it ends (`"leg": name`), then --
+the LAST line, the one the driver parses, kept below 6 KB -- the headline with one short
+object per further workload under "also".  The headline's `value`, `ms_per_step`,
+`kernel.ms` and `roofline` all come from ONE timed region: `--steps` passes, one batch
+of rays on the GPU at a time (BASELINE's "1 M parallel rays"); what several batches in
+flight on streams of their own reach is measured in a second region and reported
+beside it (`in_flight`).
 """
 from __future__ import annotations
 
@@ -44,6 +50,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_CLOCK_HZ = 2.4e9       # MI355X peak engine clock (MI355X_MICROARCH.md)
 TRACE_KERNEL = "k_trace (phase A: every ray by the closed form up to its hand-over step, 32 or 512; phase B: the rest on their lines) + k_cross (every crossing, packed)"
 STEP_KERNELS = "k_step_fast + k_bisect per generation (single steps, directions drawn in the kernel)"
+STEP_N_KERNELS = "k_step_fast + k_bisect per generation (turtle_stepper_step_n, TURTLE_AMD_STEP_RESUME, the caller's directions)"
 WALK_KERNEL = "k_walk (a ray's whole walk in one launch: state in registers, directions drawn in the kernel)"
 SEED = 0x5EED2026
 PARITY_RAYS = 100_000
@@ -59,7 +66,7 @@ WORKLOADS = {
            "C4: 12.5M rays/GPU (100M on 8 GPUs, block-sharded), one 3601x3601 SRTMGL1 tile "
            "replicated, trace to first boundary, RCCL reduce of hits + path-length histogram"),
     "c5": ((40, 0, 10, 10), True, 10_000_000,
-           "C5: 10M scattering rays/GPU, 256 single steps each with a new isotropic "
+           "C5: 10M scattering rays/GPU, {steps} single steps each with a new isotropic "
            "direction per step (Philox(ray, step)), 10x10 mosaic of 3601x3601 tiles"),
 }
 
@@ -260,28 +267,24 @@ def cpu_baseline(terrain, pos, d, cores):
                                 np.array_equal(a["length"], res["length"]))
         a = run(pos[: max(1, n_rays // cores)], d[: max(1, n_rays // cores)], 1.0, 1)
         out["ref_one_core"] = a["total_steps"] / a["seconds"]
-        out["ref_how"] = ("one turtle_stack with lock / unlock shared by the threads, a client per "
-                          "worker (the reference's threaded example)" if terrain.use_stack else
-                          "one stepper per thread over a shared map")
+        out["ref_how"] = ("a locked stack shared, a client per thread" if terrain.use_stack else
+                          "a stepper per thread over a shared map")
     return out, res
 
 
 def cpu_baseline_entry(cpu, cores, n_rays):
-    port = (f"oracle/ C restatement, {cores} pthreads: {cpu['range0']:.4g} steps/s with the "
-            f"exact transform (range 0), {cpu['range1']:.4g} at range 1, "
-            f"{cpu['one_core']:.4g} on one core")
+    """`sample` says what was timed in under 200 characters; the other figures are fields"""
+    port = {"port_range0": cpu["range0"], "port_range1": cpu["range1"], "port_one_core": cpu["one_core"]}
     if "ref_range1" in cpu:
         return {"value": cpu["ref_range1"], "unit": "ray-steps/s", "cores": cores, "kind": "reference",
-                "sample": f"{n_rays} rays of the same recipe through the reference itself "
-                          f"(oracle/_ref, turtle_stepper_step in the example harness's loop, "
-                          f"{cpu.get('ref_how', 'one stepper per thread')}, {cores} pthreads, its "
-                          f"default local range of 1 m); "
-                          f"with the exact transform (range 0, what the GPU computes): "
-                          f"{cpu['ref_range0']:.4g} steps/s; one core: {cpu['ref_one_core']:.4g}; "
-                          f"results equal to the restatement's bit for bit: {cpu['ref_equal']}. "
-                          f"For comparison the {port}"}
+                "sample": f"{n_rays} rays of the same recipe through the reference itself (oracle/_ref), "
+                          f"{cores} pthreads, {cpu.get('ref_how', 'one stepper per thread')}, its default "
+                          f"local range of 1 m",
+                "range0": cpu["ref_range0"], "one_core": cpu["ref_one_core"],
+                "equal_to_the_restatement_bit_for_bit": cpu["ref_equal"], **port}
     return {"value": cpu["range0"], "unit": "ray-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_rays} rays of the same recipe, {port}"}
+            "sample": f"{n_rays} rays of the same recipe, oracle/ C restatement, {cores} pthreads, exact "
+                      f"transform (range 0)", **port}
 
 
 def run_workload(name, args, env, headline):
@@ -319,6 +322,9 @@ def run_workload(name, args, env, headline):
     assert int((di != 0).sum()) == 0
     del t_lat, t_lon, t_az, t_el
     scatter = name == "c5"
+    gens = getattr(args, "step_n", 0) if scatter else 0     # > 0: the walk through turtle_stepper_step_n
+    if gens:
+        args.scatter_steps = gens
     # ---- batches in flight: a stepper, a stream and a set of arrays each (one stepper is
     # one stream of calls, as one turtle_stepper is one thread's in the reference) ----
     width = args.in_flight if args.in_flight > 0 else (1 if (scatter or (use_stack and args.stack_size)) else 3)
@@ -337,6 +343,7 @@ def run_workload(name, args, env, headline):
             self.length = torch.empty(n, dtype=torch.float64, device=dev)
             self.nsteps = torch.empty(n, dtype=torch.int32, device=dev)
             self.tally = torch.zeros(t_size, dtype=torch.int64, device=dev)
+            self.gen_ms = []
 
         def enter(self):
             torch.cuda.set_stream(self.stream)
@@ -348,6 +355,37 @@ def run_workload(name, args, env, headline):
     first_ray = rank * n
     walk_state = {}
 
+    dirs = []
+    if gens:
+        # the CALLER's directions, as a Monte-Carlo would hand them over: drawn beforehand on the
+        # device (the library's Philox, so that the CPU checker can draw the same)
+        dirs = [TA.isotropic(n, SEED, k, first_ray=first_ray) for k in range(gens)]
+
+    def step_walk(f, count):
+        """a pass of the step_n leg: sample the origins, then `gens` generations of
+        turtle_stepper_step_n, each resumed from the sample the one before returned
+        (TURTLE_AMD_STEP_RESUME), latitude and longitude not asked for.  `count`: an UNTIMED
+        replica that also sums what the caller of a real walk would (lengths, steps)."""
+        st = f.stepper.step(f.pos, None, outputs=False)
+        if count:
+            total = torch.zeros(n, dtype=torch.float64, device=dev)
+            taken = torch.zeros(n, dtype=torch.int32, device=dev)
+        else:
+            f.gen_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            f.gen_ev[0].record()
+        for k in range(gens):
+            if count:
+                alive = st["index"][:, 0] >= 0
+            st = f.stepper.step(st["position"], dirs[k], resume=st)
+            if count:
+                total += torch.where(alive, st["step"], torch.zeros_like(total))
+                taken += alive.to(torch.int32)
+        if count:
+            return {"index": st["index"].clone(), "length": total, "steps": taken}
+        f.gen_ev[1].record()
+        f.gen_ms.append(f.gen_ev)
+        return None
+
     if args.sort_steps and not scatter:
         pos.copy_(pos0)
         stepper.trace_into(pos, direction, index, length, nsteps, args.max_steps)
@@ -357,6 +395,10 @@ def run_workload(name, args, env, headline):
     def one_pass(f):
         if not scatter:
             f.stepper.trace_into(f.pos, direction, f.index, f.length, f.nsteps, args.max_steps)
+            return
+        if gens:
+            step_walk(f, False)
+            f.walk = walk_state["w"]
             return
         # C5: turtle_stepper_scatter_n samples the origins, then takes scatter-steps
         # single steps per ray, each resumed from the sample of the one before,
@@ -387,52 +429,65 @@ def run_workload(name, args, env, headline):
             reduce_tally(f)
         flights[0].enter()
 
-    steps = args.steps if headline else 1
+    paged = bool(use_stack and args.stack_size)
+    steps = args.steps if headline else (1 if (scatter or paged) else 3)
     warmup = args.warmup if headline else 1
     torch.cuda.synchronize()                 # the rays are there for every stream
+    if gens:
+        flights[0].pos.copy_(pos0)
+        walk_state["w"] = step_walk(flights[0], True)
     passes(max(warmup, width), flights)      # (every stepper's scratch comes with its first pass)
-    if not headline and width > 1:
-        steps = 3 * width                    # an `also` leg with batches in flight: a few passes
 
     def new_events(count):
         return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 for _ in range(count)]
-    ev = new_events(steps)
-    TA.set_in_flight(width)                  # (a hint: the kernels share the SIMDs with their like)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    passes(steps, flights, ev)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    TA.set_in_flight(1)
-    t_all = torch.tensor([elapsed], dtype=torch.float64,
-                         device=dev if env["backend"] == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-    elapsed = float(t_all.item())
 
-    stats = stepper.trace_stats()            # of the last pass on this rank
-    total_steps_per_pass = int(tally[t_steps].item())   # all ranks (all-reduced)
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    kernel_ms_in_flight = None
-    if width > 1:
-        # the kernels of ONE pass, alone on the GPU (what profiles/ hold and the roofline is
-        # about): a few passes more, one batch in flight, outside the timed region
-        kernel_ms_in_flight = kernel_ms
-        alone = new_events(max(3, min(steps, 10)))
-        passes(len(alone), flights[:1], alone)
+    def region(count, lanes):
+        """`count` passes bracketed by a barrier + synchronize on both sides; the MAX over
+        ranks of the wall time, and each pass's own HIP events (on its launch stream)"""
+        ev = new_events(count)
+        TA.set_in_flight(len(lanes))         # (a hint: the kernels share the SIMDs with their like)
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in alone]))
+        t0 = time.perf_counter()
+        passes(count, lanes, ev)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        TA.set_in_flight(1)
+        t_all = torch.tensor([dt], dtype=torch.float64,
+                             device=dev if env["backend"] == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        return float(t_all.item()), float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # THE timed region: one batch on the GPU at a time.  value, ms_per_step, kernel.ms and
+    # the roofline are all this region's.
+    elapsed, kernel_ms = region(steps, flights[:1])
+    stats = stepper.trace_stats()            # of the last pass on this rank
+    if gens:
+        # step_n keeps no totals: the replica's count, and SURVEY's 1.05 samples a step
+        taken = int(walk_state["w"]["steps"].sum(dtype=torch.int64).item())
+        stats = {"rays": n, "steps": taken, "samples": int(round(1.05 * taken)), "capped": 0}
+        ms = [a.elapsed_time(b) for a, b in flights[0].gen_ms[-steps:]]
+        gen_ms = float(np.mean(ms)) / gens
+    total_steps_per_pass = int(tally[t_steps].item())   # all ranks (all-reduced)
+    flight = None
+    if width > 1:
+        # beside it: `width` batches in flight (a trace ends with a few rays of thousands of
+        # steps, which then step beside the bulk of the next batch); same bits
+        count = max(steps, 3 * width)
+        dt, span = region(count, flights)
+        flight = {"batches": width, "passes": count, "ms_per_pass": 1e3 * dt / count,
+                  "value": total_steps_per_pass * count / dt, "ms_a_pass_spans": span}
     out = None
     if rank == 0:
         value = total_steps_per_pass * steps / elapsed
         # a walk over resident tiles is ONE launch (k_walk); over paged tiles, or with
         # TURTLE_AMD_WALK=steps, two kernels per generation
-        by_steps = bool(args.stack_size) or os.environ.get("TURTLE_AMD_WALK") == "steps"
+        by_steps = bool(args.stack_size) or os.environ.get("TURTLE_AMD_WALK") == "steps" or bool(gens)
         launches = (args.scatter_steps if by_steps else 1) if scatter else 1
         if scatter:
             # SURVEY 8d, single-step batch mode: 8 B of nodes per sample + 48 in (pos, dir
@@ -441,9 +496,9 @@ def run_workload(name, args, env, headline):
             samples_per_step = stats["samples"] / max(1, stats["steps"])
             alg_bytes = (8.0 * samples_per_step + 88.0) * stats["steps"]
             per_launch = alg_bytes / launches
-            kernel = {"name": STEP_KERNELS if by_steps else WALK_KERNEL, "ms": kernel_ms,
-                      "launches_per_step": launches,
-                      "ms_per_generation": kernel_ms / args.scatter_steps,
+            kernel = {"name": (STEP_N_KERNELS if gens else STEP_KERNELS) if by_steps else WALK_KERNEL,
+                      "ms": kernel_ms, "launches_per_step": launches,
+                      "ms_per_generation": gen_ms if gens else kernel_ms / args.scatter_steps,
                       "steps_per_pass": stats["steps"], "samples_per_pass": stats["samples"],
                       "samples_per_step": samples_per_step,
                       "gpu_steps_per_s": stats["steps"] / (kernel_ms * 1e-3)}
@@ -460,7 +515,7 @@ def run_workload(name, args, env, headline):
                       "rays_stopped_at_max_steps": stats["capped"]}
             bytes_note = "SURVEY 8d trace mode: 8 B x samples + 64 B x rays"
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src, valu = measured_traffic(name, n, TA.get_math())
+        traffic, traffic_src, valu = measured_traffic(name + ("_step_n" if gens else ""), n, TA.get_math())
         if use_stack and args.stack_size:
             # the counters were taken with every tile resident: they say nothing of a paged pass
             traffic, traffic_src, valu = None, None, None
@@ -468,38 +523,24 @@ def run_workload(name, args, env, headline):
         valu_frac = (4.0 * valu / (simds * kernel_ms * 1e-3 * VALU_CLOCK_HZ)) if valu else None
         out = {
             "value": value, "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
-            "config": {"workload": text + (f" -- stack_size {args.stack_size}: tiles paged host->HBM "
+            "config": {"workload": text.replace("{steps}", str(args.scatter_steps)) +
+                       (" -- through turtle_stepper_step_n, the caller's directions" if gens else "") + (f" -- stack_size {args.stack_size}: tiles paged host->HBM "
                                            f"by demand, {stepper.rounds} rounds in the last pass"
                                            if (use_stack and args.stack_size) else ""),
                        "rays_per_gpu": n, "max_steps": args.max_steps,
                        "slope": 0.4, "resolution": 1e-2, "math": TA.get_math(),
-                       "parallelism": f"rays x{world}", "in_flight": width},
+                       "parallelism": f"rays x{world}", "in_flight": 1},
             "kernel": kernel,
-            "in_flight": {"batches": width,
-                          "note": ("passes of one batch each, taken in turn by `batches` steppers on streams of "
-                                   "their own (one stepper is one stream of calls): a trace ends with a few "
-                                   "rays of thousands of steps, which then step beside the bulk of the next "
-                                   "batch.  `value` and `ms_per_step` are the whole timed region's; `kernel` and "
-                                   "`roofline` are one pass alone on the GPU, measured with HIP events "
-                                   + ("in the timed region itself" if width == 1 else
-                                      "right after it (under overlap a pass's own events span "
-                                      f"{kernel_ms_in_flight:.3f} ms)")),
-                          "ms_per_step_alone": kernel_ms,
-                          "value_alone": stats["steps"] * world / (kernel_ms * 1e-3),
-                          "algorithmic_gbs": alg_bytes * steps / elapsed / 1e9,
-                          "algorithmic_frac_of_hbm": alg_bytes * steps / elapsed / 1e9 / HBM_PEAK_GBS},
+            "in_flight": flight,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": per_launch,
-                         "valu_issue_frac": valu_frac,
-                         "note": f"achieved = algorithmic bytes ({bytes_note}) / kernel time (HIP "
-                                 "events on the launch stream); traffic = FETCH_SIZE+WRITE_SIZE "
-                                 "bytes per launch (PMC, offline, same kernel source: null when "
-                                 "the source has changed since).  A trace is fp64-latency shaped, "
-                                 "not bandwidth shaped; the algorithmic bytes of a walk are SURVEY's, "
-                                 "which stream the ray state at every step -- k_walk keeps it in "
-                                 "registers, so what it really moves is far less: see DESIGN.md"},
+                         "valu_issue_frac": valu_frac, "bytes": bytes_note,
+                         # where bandwidth is the question (single steps): what the counters say
+                         # the launch really moved, over its time, against the HBM peak
+                         "traffic_frac_of_hbm": (traffic / (kernel_ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                 if (traffic and scatter) else None)},
             "tally": {"hits": [int(v) for v in tally[t_hits].tolist()],
                       "sha256": hashlib.sha256(tally.cpu().numpy().tobytes()).hexdigest()[:16]},
         }
@@ -573,6 +614,85 @@ def run_workload(name, args, env, headline):
     return out
 
 
+DEFAULT_ALSO = "c3,c3@8,c4,c5,c5!step_n,c2!strict,c3!strict"
+LINE_LIMIT = 6000           # bytes of the last stdout line (the driver keeps an 8 KB tail)
+
+
+def _short(text, limit=200):
+    return text if len(text) <= limit else text[: limit - 3] + "..."
+
+
+def _round(x, digits=5):
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _round(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round(v, digits) for v in x]
+    return x
+
+
+def short_leg(r):
+    """one short object per further workload: numbers only"""
+    out = {"value": r["value"], "ms_per_pass": r["ms_per_step"], "passes": r["steps"],
+           "kernel_ms": r["kernel"]["ms"], "frac": r["roofline"]["frac"],
+           "traffic": r["roofline"]["traffic"]}
+    if r["kernel"].get("ms_per_generation") is not None:
+        out["ms_per_generation"] = r["kernel"]["ms_per_generation"]
+    if r["roofline"].get("traffic_frac_of_hbm") is not None:
+        out["traffic_frac_of_hbm"] = r["roofline"]["traffic_frac_of_hbm"]
+    if r.get("in_flight"):
+        out["in_flight"] = {k: r["in_flight"][k] for k in ("batches", "value", "ms_per_pass")}
+    if "parity" in r:
+        out["medium_mismatch"] = r["parity"]["medium_mismatch"]
+        out["beyond_1e-6"] = r["parity"]["beyond_1e-6"]
+        out["parity_rays"] = r["parity"]["rays"]
+    if "cpu_baseline" in r:
+        out["cpu"] = {"value": r["cpu_baseline"]["value"], "kind": r["cpu_baseline"]["kind"],
+                      "cores": r["cpu_baseline"]["cores"]}
+    return out
+
+
+def final_line(head, extra, args, world, backend, comm_size):
+    """The LAST stdout line: the headline (everything from one timed region, one batch at a
+    time) and one short object per further workload; the full records went out before it."""
+    kernel = head["kernel"]
+    roof = head["roofline"]
+    line = {
+        "metric": "ray-steps/sec (whole node) through 3601^2 SRTM tile",
+        "value": head["value"], "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {k: head["config"][k] for k in ("workload", "rays_per_gpu", "max_steps", "math",
+                                                   "parallelism", "in_flight")},
+        "backend": backend if world > 1 else None, "comm_world_size": comm_size,
+        "kernel": {"name": _short(kernel["name"], 120), "ms": kernel["ms"],
+                   "launches_per_step": kernel["launches_per_step"],
+                   "steps_per_launch": kernel.get("steps_per_launch", kernel.get("steps_per_pass")),
+                   "samples_per_step": kernel["samples_per_step"]},
+        "in_flight": ({k: head["in_flight"][k] for k in ("batches", "value", "ms_per_pass")}
+                      if head.get("in_flight") else None),
+        "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic",
+                                          "traffic_source", "valu_issue_frac")},
+        "tally": head["tally"],
+    }
+    line["config"]["workload"] = _short(line["config"]["workload"], 160)
+    if "parity" in head:
+        line["parity"] = {k: v for k, v in head["parity"].items() if k not in ("checker", "note")}
+    if "cpu_baseline" in head:
+        c = head["cpu_baseline"]
+        line["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"],
+                                "kind": c["kind"], "sample": _short(c["sample"], 200)}
+    if extra:
+        line["also"] = {k: short_leg(r) for k, r in extra.items()}
+    line = _round(line)
+    if len(json.dumps(line)) >= LINE_LIMIT:      # never lose the headline to a long line
+        line["also"] = {k: {"value": v["value"], "ms_per_pass": v["ms_per_pass"]}
+                        for k, v in line.get("also", {}).items()}
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -603,6 +723,10 @@ def main():
                     help="batches in flight: steppers on streams of their own that take the passes in "
                          "turn, so that the few long rays a trace ends with step beside the bulk of the "
                          "next batch (0: three for a trace over resident terrain, else one)")
+    ap.add_argument("--step-n", type=int, default=0,
+                    help="c5 only: the walk through turtle_stepper_step_n with TURTLE_AMD_STEP_RESUME and "
+                         "the CALLER's directions (drawn beforehand), this many generations a pass")
+    ap.add_argument("--generations", type=int, default=64, help="generations of the default c5!step_n leg")
     ap.add_argument("--tiles", choices=("auto", "hgt", "tif"), default="auto",
                     help="tile files: SRTM's .hgt, ASTER-GDEM2's GeoTIFF-16 (auto: tif for c5, hgt else)")
     args = ap.parse_args()
@@ -655,15 +779,20 @@ def main():
 
     head_name = args.workload or "c2"
     head = run_workload(head_name, args, env, headline=True)
+    if rank == 0:
+        print(json.dumps({"leg": head_name, **head}), flush=True)
     also = args.also
     if also is None:
-        also = "c3,c3@8,c4,c5,c2!strict,c3!strict" if (args.workload is None and world == 1) else "none"
+        also = DEFAULT_ALSO if (args.workload is None and world == 1) else "none"
     extra = {}
-    for name in [w for w in also.split(",") if w and w != "none"]:
+    for leg in [w for w in also.split(",") if w and w != "none"]:
+        name = leg
         sub = argparse.Namespace(**vars(args))
-        sub.rays, sub.blocks, sub.sort, sub.sort_steps, sub.stack_size = 0, 1, 0, 0, 0
+        sub.rays, sub.blocks, sub.sort, sub.sort_steps, sub.stack_size, sub.step_n = 0, 1, 0, 0, 0, 0
         if name.endswith("@8"):      # C3's second leg: the same workload, 8 of its 16 tiles resident
             name, sub.stack_size = name[:-2], 8
+        if name.endswith("!step_n"):  # C5 through turtle_stepper_step_n, the caller's directions
+            name, sub.step_n = name[:-7], args.generations
         strict = name.endswith("!strict")   # the reference's arithmetic, operand for operand
         if strict:
             name, sub.no_cpu = name[:-7], True
@@ -674,28 +803,14 @@ def main():
             if strict:
                 TA.set_math(os.environ.get("TURTLE_AMD_MATH", "fast"))
         if rank == 0:
-            extra[name + (f"_stack_size_{sub.stack_size}" if sub.stack_size else "") + ("_strict" if strict else "")] = {"metric": "ray-steps/s", "value": r["value"], "passes": r["steps"],
-                           "ms_per_pass": r["ms_per_step"], "config": r["config"],
-                           "kernel": r["kernel"], "in_flight": r["in_flight"], "roofline": r["roofline"],
-                           **({"parity": r["parity"]} if "parity" in r else {}),
-                           **({"cpu_baseline": r["cpu_baseline"]} if "cpu_baseline" in r else {})}
+            key = (name + (f"_stack_size_{sub.stack_size}" if sub.stack_size else "")
+                   + ("_step_n" if sub.step_n else "") + ("_strict" if strict else ""))
+            print(json.dumps({"leg": key, **r}), flush=True)
+            extra[key] = r
 
     if rank == 0:
-        line = {
-            "metric": "ray-steps/sec (whole node) through 3601^2 SRTM tile",
-            "value": head["value"], "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": head["config"], "kernel": head["kernel"], "in_flight": head["in_flight"],
-            "roofline": head["roofline"], "tally": head["tally"],
-        }
-        for key in ("parity", "cpu_baseline"):
-            if key in head:
-                line[key] = head[key]
-        if extra:
-            line["also"] = extra
-        print(json.dumps(line), flush=True)
+        print(json.dumps(final_line(head, extra, args, world, env["backend"],
+                                    dist.get_world_size() if world > 1 else 1)), flush=True)
 
     if world > 1:
         dist.destroy_process_group()

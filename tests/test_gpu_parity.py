@@ -896,6 +896,37 @@ def test_plain_c_caller(tmp_path):
     assert out.returncode == 0 and "0 disagreements" in out.stdout
 
 
+def test_unmodified_reference_loop_and_the_environment_switch(tmp_path):
+    """examples/reference_loop.c uses nothing but the reference's own header and keeps its
+    per-ray loop of scalar calls.  Relinked, source unchanged: a launch a call by default; with
+    TURTLE_AMD_SCALAR=host in the environment the same binary is answered on the host (the
+    same media and step counts, path lengths within 1e-9) at a cost of the reference's order."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(tmp_path, "reference_loop")
+    lib = os.path.join(root, "turtle_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "reference_loop.c"), "-L" + lib,
+                           "-lturtle_amd", "-lm", "-Wl,-rpath," + lib, "-o", exe])
+    rows, cost = {}, {}
+    for where in ("device", "host"):
+        env = {k: v for k, v in os.environ.items() if k != "TURTLE_AMD_SCALAR"}
+        if where == "host":
+            env["TURTLE_AMD_SCALAR"] = "host"
+        out = subprocess.run([exe, "12"], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stderr[-500:]
+        rows[where] = re.findall(r"ray (\d+): medium (-?\d+) -> (-?\d+) after (\d+) steps, (\S+) m", out.stdout)
+        cost[where] = float(re.search(r"(\d+) ns a call", out.stdout).group(1))
+    assert len(rows["host"]) == 12 and len(rows["device"]) == 12
+    for a, b in zip(rows["device"], rows["host"]):
+        assert a[:4] == b[:4], (a, b)
+        assert abs(float(a[4]) - float(b[4])) <= 1e-9 * float(b[4]), (a, b)
+    print(f"scalar calls: {cost['device']:.0f} ns on the device, {cost['host']:.0f} ns on the host")
+    assert cost["host"] < 5000 < cost["device"]
+
+
 def test_c_host_with_threads_and_rccl(tmp_path):
     """examples/multi_gpu_tally.c: a C host, one thread per GPU over a shared map,
     the tally reduced with ncclAllReduce(ncclUint64) over RCCL; on this one-GPU box
@@ -934,8 +965,13 @@ def test_two_ranks_share_the_gpu_through_bench(tmp_path):
     lines = []
     for out in (two, one):
         rows = [l for l in out.stdout.splitlines() if l.startswith("{")]
-        assert out.returncode == 0 and len(rows) == 1, (out.stdout[-500:], out.stderr[-1500:])
-        lines.append(json.loads(rows[0]))
+        # the full record of the workload ("leg"), then the line the driver parses: the LAST one
+        assert out.returncode == 0 and len(rows) == 2, (out.stdout[-500:], out.stderr[-1500:])
+        assert json.loads(rows[0])["leg"] == "c2" and len(rows[-1]) < 6000
+        lines.append(json.loads(rows[-1]))
+        assert lines[-1]["kernel"]["ms"] <= lines[-1]["ms_per_step"]
+        assert lines[-1]["in_flight"]["batches"] == 3 and lines[-1]["config"]["in_flight"] == 1
+    assert lines[0]["backend"] == "gloo" and lines[0]["comm_world_size"] == 2
     assert lines[0]["n_gpus"] == 2 and lines[1]["n_gpus"] == 1
     assert lines[0]["tally"] == lines[1]["tally"]
     assert sum(lines[0]["tally"]["hits"]) == 300000
@@ -946,8 +982,8 @@ def test_two_ranks_share_the_gpu_through_bench(tmp_path):
                          capture_output=True, text=True, timeout=600, cwd=root,
                          env={k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     rows = [l for l in own.stdout.splitlines() if l.startswith("{")]
-    assert own.returncode == 0 and len(rows) == 1, (own.stdout[-500:], own.stderr[-1500:])
-    assert json.loads(rows[0])["n_gpus"] == 2 and json.loads(rows[0])["tally"] == lines[0]["tally"]
+    assert own.returncode == 0 and len(rows) == 2, (own.stdout[-500:], own.stderr[-1500:])
+    assert json.loads(rows[-1])["n_gpus"] == 2 and json.loads(rows[-1])["tally"] == lines[0]["tally"]
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "nope"],
                          capture_output=True, text=True, timeout=120, cwd=root)
     assert bad.returncode != 0

@@ -124,7 +124,11 @@ struct turtle_stack {
         /* Tiles come in through page-locked staging buffers (tiles.c): worker threads read and
          * decode the files of a round side by side, straight into the HBM layout; the upload is
          * a queued copy.  A slot is free again once the device it was copied to has drained
-         * (`stage_device`: -1 free, -2 holds a tile not uploaded yet). */
+         * (`stage_device`: -1 free, -2 holds a tile not uploaded yet, d >= 0 a copy to
+         * device d was queued and could not be waited for: free once d has drained).
+         * What a stack keeps for its lifetime: up to 16 page-locked buffers and, per
+         * device, up to 16 HBM buffers of one tile each -- 26 MB apiece for 3601 x 3601
+         * tiles, 0.4 GB of either at most; turtle_stack_clear / _destroy give them back. */
 #define TAMD_STAGE_SLOTS 16
         uint16_t * stage[TAMD_STAGE_SLOTS];
         int stage_device[TAMD_STAGE_SLOTS];
@@ -294,6 +298,7 @@ int tamd_h_stepper_position(struct turtle_stepper * stepper, double latitude, do
     double height, int layer_index, double * position, int * data_index, char * message, size_t size);
 /* stack.c: one tile into memory for the host path, the least recently used going beyond the
  * stack's size [ref stack.c:399-450]; an enum turtle_return */
-int tamd_stack_host_load(struct turtle_stack * stack, int slot, char * message, size_t size);
+int tamd_stack_host_fetch(struct turtle_stack * stack, int slot, double latitude, double longitude,
+    double * z, int * inside, char * message, size_t size);
 
 #endif

@@ -326,9 +326,13 @@ int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
                          * the tile reads "current" another thread's launches, on another
                          * stream, may read it (26 MB from page-locked memory: half a
                          * millisecond) */
-                        failed = tamd_dev_copy_async(map->d_nodes[device], map->staged, bytes, 1) ||
-                            tamd_dev_sync();
-                        tamd_stack_staged_done(map, -1);
+                        const int queued =
+                            (tamd_dev_copy_async(map->d_nodes[device], map->staged, bytes, 1) == 0);
+                        failed = !queued || tamd_dev_sync();
+                        /* a copy that was queued and could not be waited for may still be
+                         * reading the buffer: the slot is free once that device has drained
+                         * (stage_acquire), not now */
+                        tamd_stack_staged_done(map, (queued && failed) ? device : -1);
                 } else {
                         uint16_t * blocked = malloc(bytes);
                         if (blocked == NULL) {

@@ -33,16 +33,36 @@
 #include <stdlib.h>
 #include <string.h>
 
-static int g_scalar_mode = TURTLE_AMD_SCALAR_DEVICE;
+/* -1: not asked yet -- the environment decides at first use (TURTLE_AMD_SCALAR=host|device:
+ * a caller relinked against this library, source unchanged, gets the host's scalar calls by
+ * setting a variable); turtle_amd_scalar_set() wins over it, before or after */
+static int g_scalar_mode = -1;
+
+static int scalar_mode(void)
+{
+        int mode = __atomic_load_n(&g_scalar_mode, __ATOMIC_RELAXED);
+        if (mode < 0) {
+                const char * e = getenv("TURTLE_AMD_SCALAR");
+                mode = ((e != NULL) && ((strcmp(e, "host") == 0) || (strcmp(e, "HOST") == 0))) ?
+                    TURTLE_AMD_SCALAR_HOST : TURTLE_AMD_SCALAR_DEVICE;
+                int unset = -1; /* (a set() that came in between stands) */
+                if (!__atomic_compare_exchange_n(&g_scalar_mode, &unset, mode, 0, __ATOMIC_RELAXED,
+                        __ATOMIC_RELAXED))
+                        mode = unset;
+        }
+        return mode;
+}
 
 void turtle_amd_scalar_set(int mode)
 {
-        g_scalar_mode = (mode == TURTLE_AMD_SCALAR_HOST) ? TURTLE_AMD_SCALAR_HOST : TURTLE_AMD_SCALAR_DEVICE;
+        __atomic_store_n(&g_scalar_mode,
+            (mode == TURTLE_AMD_SCALAR_HOST) ? TURTLE_AMD_SCALAR_HOST : TURTLE_AMD_SCALAR_DEVICE,
+            __ATOMIC_RELAXED);
 }
-int turtle_amd_scalar_get(void) { return g_scalar_mode; }
+int turtle_amd_scalar_get(void) { return scalar_mode(); }
 
 /* do the scalar calls run here?  (and is there a device: see the header of this file) */
-int tamd_scalar_on_host(void) { return (g_scalar_mode == TURTLE_AMD_SCALAR_HOST) && (tamd_dev_init() == 0); }
+int tamd_scalar_on_host(void) { return (scalar_mode() == TURTLE_AMD_SCALAR_HOST) && (tamd_dev_init() == 0); }
 
 /* ---- WGS84 [ref ecef.c:30-38] ------------------------------------------------ */
 #define WGS_A 6378137
@@ -188,40 +208,59 @@ static int h_tile_holds(const struct turtle_map * m, double latitude, double lon
         return (hx >= 0.) && (hx < m->nx - 1) && (hy >= 0.) && (hy < m->ny - 1);
 }
 
-/* 0: *inside and *z set (z = 0 outside); else an enum turtle_return with `message` */
+/* 0: *inside and *z set (z = 0 outside); else an enum turtle_return with `message`.
+ *
+ * A stack with lock / unlock callbacks is the one threads may share [ref
+ * include/turtle.h:620-626, examples/example-pthread.c:66-125], and its tiles can go
+ * at any moment: to another thread's load here, to a batch call's page-in or trim.
+ * The reference keeps a client's tile by a count under the lock [ref stack.c:433-442];
+ * here the lookup and the interpolation hold the geometry IN USE (shared), which
+ * whoever frees a tile holds exclusively (tamd_geometry_write_begin) -- and a tile
+ * that has to be read is interpolated before that hold is given up
+ * (tamd_stack_host_fetch), so that a stack of size 1 under two threads still gets
+ * every thread its answer.  A stack without callbacks is one thread's, as in the
+ * reference, and pays for none of this. */
 int tamd_h_stack_elevation(struct turtle_stack * s, double latitude, double longitude, double * z,
     int * inside, char * message, size_t size)
 {
-        const int n = s->latitude_n * s->longitude_n;
+        const int n = s->latitude_n * s->longitude_n, shared = (s->lock != NULL);
         int i, hit = -1;
         *inside = 0, *z = 0.;
         /* (a NaN passes the reference's test of its head tile, which is written the other way
          * round [ref stack.c:310-311], and is then outside that tile [ref map.c:233-240]; with
          * no tile in memory it indexes the directory with (int)NaN) */
         if (isnan(latitude) || isnan(longitude)) return 0;
+        if (shared) tamd_geometry_use_begin();
         /* the tile most recently used whose box holds the point [ref stack.c:300-335: the
          * head, then down the list, a hit moving to its head]: stamps order the list here */
         for (i = 0; i < n; i++) {
                 if ((s->tile[i] == NULL) || !h_tile_holds(s->tile[i], latitude, longitude)) continue;
                 if ((hit < 0) || (s->stamp[i] > s->stamp[hit])) hit = i;
         }
+        int rc = 0;
         if (hit < 0) { /* [ref stack.c:399-450] the directory names the file; it is loaded */
-                if ((longitude < s->longitude_0) || (latitude < s->latitude_0)) return 0;
-                const int ix = (int)((longitude - s->longitude_0) / s->longitude_delta);
-                if (ix >= s->longitude_n) return 0;
-                const int iy = (int)((latitude - s->latitude_0) / s->latitude_delta);
-                if (iy >= s->latitude_n) return 0;
-                hit = iy * s->longitude_n + ix;
-                if (s->path[hit] == NULL) return 0;
-                if (s->tile[hit] == NULL) {
-                        const int rc = tamd_stack_host_load(s, hit, message, size);
-                        if (rc != TURTLE_RETURN_SUCCESS) return rc;
+                if ((longitude >= s->longitude_0) && (latitude >= s->latitude_0)) {
+                        const int ix = (int)((longitude - s->longitude_0) / s->longitude_delta);
+                        const int iy = (int)((latitude - s->latitude_0) / s->latitude_delta);
+                        if ((ix < s->longitude_n) && (iy < s->latitude_n) &&
+                            (s->path[iy * s->longitude_n + ix] != NULL))
+                                hit = iy * s->longitude_n + ix;
+                }
+                if ((hit >= 0) && (s->tile[hit] == NULL)) {
+                        if (shared) tamd_geometry_use_end();
+                        return tamd_stack_host_fetch(s, hit, latitude, longitude, z, inside, message, size);
                 }
         }
-        s->stamp[hit] = ++s->clock; /* [ref stack.c:391-396] */
-        double elevation;
-        if (tamd_h_map_elevation(s->tile[hit], longitude, latitude, &elevation)) *z = elevation, *inside = 1;
-        return 0;
+        if (hit >= 0) {
+                /* [ref stack.c:391-396] */
+                __atomic_store_n(&s->stamp[hit], __atomic_add_fetch(&s->clock, 1, __ATOMIC_RELAXED),
+                    __ATOMIC_RELAXED);
+                double elevation;
+                if (tamd_h_map_elevation(s->tile[hit], longitude, latitude, &elevation))
+                        *z = elevation, *inside = 1;
+        }
+        if (shared) tamd_geometry_use_end();
+        return rc;
 }
 
 /* ---- the stepper [ref stepper.c:687-931] ------------------------------------------- */

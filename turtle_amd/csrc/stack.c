@@ -520,8 +520,11 @@ static int stack_page_in(struct turtle_stack * s, const unsigned * wanted,
 
 /* One tile for the host's scalar path (scalar.c), as the reference loads one [ref
  * stack.c:428-446]: beyond the stack's size the least recently used tiles go first
- * (none that a thread has just paged in for its round). */
-int tamd_stack_host_load(struct turtle_stack * s, int slot, char * message, size_t size)
+ * (none that a thread has just paged in for its round) -- and the point is
+ * interpolated in it BEFORE the exclusive hold on the geometry is given up: another
+ * thread's load may take the tile away the moment it is. */
+int tamd_stack_host_fetch(struct turtle_stack * s, int slot, double latitude, double longitude,
+    double * z, int * inside, char * message, size_t size)
 {
         const int n = s->latitude_n * s->longitude_n, budget = tamd_stack_budget(s);
         if ((s->lock != NULL) && (s->lock() != 0)) {
@@ -541,6 +544,12 @@ int tamd_stack_host_load(struct turtle_stack * s, int slot, char * message, size
                         stack_drop_tile(s, out);
                 }
                 rc = stack_load_tiles(s, &slot, 1, message, size);
+        }
+        if (rc == TURTLE_RETURN_SUCCESS) {
+                s->stamp[slot] = ++s->clock; /* [ref stack.c:391-396] */
+                double elevation;
+                if (tamd_h_map_elevation(s->tile[slot], longitude, latitude, &elevation))
+                        *z = elevation, *inside = 1;
         }
         tamd_geometry_write_end();
         if ((s->unlock != NULL) && (s->unlock() != 0) && (rc == TURTLE_RETURN_SUCCESS)) {

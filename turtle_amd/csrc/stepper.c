@@ -532,6 +532,7 @@ static int stepper_rounds(struct turtle_stepper * stepper, long n, stepper_round
         struct tamd_pager pager;
         memset(&pager, 0, sizeof(pager));
         message[0] = 0;
+        int paged = 0; /* did this call bring tiles in? */
         int rc = tamd_stepper_flatten(stepper, message, size);
         if (rc != 0) return (rc < 0) ? TURTLE_RETURN_LIBRARY_ERROR : rc;
         if (stepper_is_paged(stepper) && tamd_pager_begin(&pager, n, stepper->n_table))
@@ -566,6 +567,7 @@ static int stepper_rounds(struct turtle_stepper * stepper, long n, stepper_round
                         break;
                 }
                 int code = 0;
+                paged = 1;
                 const int got = stepper_page_in(stepper, pager.wanted, pager.pinned, &code,
                     message, size);
                 if (trace_rounds) {
@@ -588,7 +590,10 @@ static int stepper_rounds(struct turtle_stepper * stepper, long n, stepper_round
         }
         tamd_pager_end(&pager);
         stepper->last_rounds = (pager.rounds > 0) ? pager.rounds : 1;
-        if (pager.rounds > 1) {
+        if (paged) {
+                /* whatever the call came to: the tiles this thread had brought in for a
+                 * round that will not run are anybody's again, and the stacks go back to
+                 * their sizes (a pin never outlives the call that set it) */
                 int i;
                 for (i = 0; i < stepper->n_data; i++)
                         if (stepper->data[i].kind == TAMD_STACK) tamd_stack_trim(stepper->data[i].stack);
