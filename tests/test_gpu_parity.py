@@ -49,7 +49,9 @@ def check_trace(t, ref_index, ref_length, ref_nsteps, what, allow=0):
     # data index and step count: equal except where a last-ulp difference
     # moves a sample across a cell edge or a bisection bracket by one
     ds = np.abs(np.asarray(t["n_steps"])[ok] - ref_nsteps[ok])
-    assert (ds <= 1).all() and (ds != 0).mean() < 1e-2, f"{what}: step counts differ"
+    # (logged on C2: 3 rays of a million; the allowance is a ten-thousandth of the rays, at least one)
+    assert (ds <= 1).all() and (ds != 0).sum() <= max(1, int(1e-4 * ds.size)), \
+        f"{what}: step counts differ on {int((ds != 0).sum())} rays of {ds.size}"
     return rel.max()
 
 

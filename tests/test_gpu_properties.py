@@ -16,6 +16,7 @@ import terrains as T
 pytestmark = pytest.mark.gpu
 
 N = 1_000_000
+HAND_OVER_MOVED = 4     # rays of creep_probe.py's batches whose step count may move with the hand-over
 
 
 @pytest.fixture(scope="module")
@@ -220,4 +221,6 @@ def test_hand_over_step_moves_no_result(tmp_path):
             rel = np.abs(r[f"{tag}_length"] - base[f"{tag}_length"]) / np.maximum(base[f"{tag}_length"], 1.0)
             assert rel.max() < 1e-7, (park, tag, rel.max())
             # a grazing ray may take a step more or less; the others take the same number
-            assert (r[f"{tag}_n_steps"] != base[f"{tag}_n_steps"]).mean() < 1e-3, (park, tag)
+            moved = int((r[f"{tag}_n_steps"] != base[f"{tag}_n_steps"]).sum())
+            print(f"hand-over at {park}, {tag}: {moved} of {base[f'{tag}_n_steps'].size} rays take another step count")
+            assert moved <= HAND_OVER_MOVED, (park, tag, moved)
