@@ -120,11 +120,42 @@ def test_creep_loop_changes_no_bit(tmp_path):
     for lanes, go in (("0", "0"), ("8", "0"), ("8", "24"), ("64", "0"), ("8", "48"), ("0", "8")):
         out = os.path.join(tmp_path, f"lanes{lanes}_{go}.npz")
         work = os.path.join(tmp_path, f"work{lanes}_{go}")
-        env = dict(os.environ, TURTLE_AMD_CREEP_LANES=lanes, TURTLE_AMD_DENSE_GO=go)
+        # (each lane keeps its ray here: with the block's pool a lean wave steps whatever these say)
+        env = dict(os.environ, TURTLE_AMD_CREEP_LANES=lanes, TURTLE_AMD_DENSE_GO=go, TURTLE_AMD_POOL="0")
         subprocess.run([sys.executable, os.path.join(here, "creep_probe.py"), out, work],
                        check=True, env=env, timeout=300)
         results[(lanes, go)] = dict(np.load(out))
     base = results[("0", "0")]
+    assert base["map_n_steps"].max() > 2000 and base["stack_n_steps"].max() > 2000
+    for which, r in results.items():
+        for key, ref in base.items():
+            assert np.array_equal(r[key], ref), (which, key)
+
+
+def test_ray_pool_changes_no_bit(tmp_path):
+    """Round 4: the four waves of a block of the lined pass exchange rays through a pool in LDS, so
+    that lean steps run with every lane going and general iterations for a full wave of rays that
+    need one (device.hip, RayPool).  Which lane or wave takes a step of a ray changes no bit of it:
+    the batch of test_creep_loop_changes_no_bit -- rays of thousands of steps, one map and a regular
+    stack -- with the pool off (and the lean loop off: the closed form's and the line's general
+    iterations only), with the pool on at its defaults, and on with other thresholds of the loop
+    that runs once the pass is down to its last rays."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    results = {}
+    for tag, env in (("off", dict(TURTLE_AMD_POOL="0", TURTLE_AMD_CREEP_LANES="0", TURTLE_AMD_DENSE_GO="0")),
+                     ("off, lean loop at its defaults", dict(TURTLE_AMD_POOL="0")),
+                     ("on", dict(TURTLE_AMD_POOL="1")),
+                     ("on, dense", dict(TURTLE_AMD_POOL="1", TURTLE_AMD_CREEP_LANES="64")),
+                     ("on, no lean loop at the end", dict(TURTLE_AMD_POOL="1", TURTLE_AMD_CREEP_LANES="0",
+                                                         TURTLE_AMD_DENSE_GO="0"))):
+        out = os.path.join(tmp_path, f"pool{len(results)}.npz")
+        subprocess.run([sys.executable, os.path.join(here, "creep_probe.py"), out,
+                        os.path.join(tmp_path, f"work{len(results)}")],
+                       check=True, env=dict(os.environ, **env), timeout=300)
+        results[tag] = dict(np.load(out))
+    base = results["off"]
     assert base["map_n_steps"].max() > 2000 and base["stack_n_steps"].max() > 2000
     for which, r in results.items():
         for key, ref in base.items():

@@ -1988,6 +1988,83 @@ enum { ST_INIT = 0, ST_STEP = 1, ST_BISECT = 2 };
  * resumed after a boundary, or after parking) */
 enum { TRACE_CARRY_MEDIUM = 1 };
 
+/* ---- a workgroup's pool of rays in LDS (round 4) --------------------------
+ *
+ * The lined pass alternates two kinds of work that want different lanes: LEAN
+ * steps (a ray on its line over one grid: ~45 vector instructions a step, for
+ * the lanes whose line and cell still serve) and GENERAL iterations (a closed
+ * form that lays a new line, a new ray's first sample, a crossing to list:
+ * ~1 000 instructions for the whole wave, whoever needs them).  With a ray
+ * fixed to its lane, a group of lean steps ran for the lanes still on their
+ * lines while the others waited, and a general iteration for the lanes that
+ * needed one while the others took a single step or none: measured on C2
+ * (round 3) 45 % of the lanes occupied and 5.6 x the wave-instructions the lean
+ * steps alone would take.
+ *
+ * So the four waves of a block exchange rays through LDS.  Before each piece of
+ * work a wave looks at what its lanes hold and at the pool and takes a ROLE:
+ *   LEAN     its rays that need a general iteration go to the pool's `service`
+ *            list, rays that are `ready` to step come out of the pool into the
+ *            free lanes, and the wave runs a group of lean steps, all lanes going;
+ *   SERVICE  its ready rays go to the pool's `ready` list, rays that wait for a
+ *            general iteration come out of the pool (then new rays from the
+ *            batch's queue), and the wave runs one general iteration for a full
+ *            wave of rays that need it;
+ *   AS IS    (the end of a pass: the batch's queue is dry and this wave and the
+ *            pool hold less than a wave of rays) nothing goes to the pool, rays
+ *            left there come out, and the wave does what it did before round 4.
+ * A ray is a record of 27 words (position, direction, path length, step, its
+ * line, its cell's nodes, its counters); records move under one lock a block
+ * (held for the copy: a few hundred cycles, four waves).  Which lane or wave
+ * takes a step of a ray never changed a bit of it (the same functions on the
+ * same values), and does not now: `test_ray_pool_changes_no_bit`.
+ *
+ * A kernel must always end: a wave leaves when the batch's queue is dry, its
+ * lanes are empty and so is the pool -- a ray in the pool was put there by a
+ * wave that is still running and looks at the pool again before it leaves. */
+#ifndef TRACE_POOL
+#define TRACE_POOL 1
+#endif
+#ifndef TRACE_POOL_SLOTS
+#define TRACE_POOL_SLOTS 192
+#endif
+#ifndef TRACE_POOL_LEAN_MIN
+#define TRACE_POOL_LEAN_MIN 48
+#endif
+#ifndef TRACE_POOL_REFILL_FREE
+#define TRACE_POOL_REFILL_FREE 64
+#endif
+/* -DTRACE_POOL_STATS: what the waves of a pooled pass do, summed over the launch (a diagnostic
+ * build: scripts/exp_pool_stats.py reads the counters) */
+#ifdef TRACE_POOL_STATS
+__device__ unsigned long long g_pool_stats[32];
+#define PSTAT(i, v) (pstat_[i] += (unsigned long long)(v))
+#define PSTAT_CLOCK() __builtin_amdgcn_s_memtime()
+#else
+#define PSTAT(i, v) ((void)0)
+#define PSTAT_CLOCK() 0ull
+#endif
+constexpr int kPoolSlots = TRACE_POOL_SLOTS;
+constexpr int kPoolLeanMin = TRACE_POOL_LEAN_MIN;       /* ready rays for which a wave turns LEAN */
+constexpr int kPoolRefillFree = TRACE_POOL_REFILL_FREE; /* free slots below which no new ray is drawn */
+constexpr int kPoolDoubles = 23, kPoolInts = 8; /* a ray's record: 216 bytes */
+enum { POOL_READY = 0, POOL_SERVICE = 1 };
+enum { ROLE_AS_IS = 0, ROLE_LEAN = 1, ROLE_SERVICE = 2 };
+struct RayPool {
+        double d[kPoolDoubles][kPoolSlots]; /* field by field: a wave's lanes move 64 slots at once */
+        int i[kPoolInts][kPoolSlots];
+        unsigned short free_slot[kPoolSlots];    /* a stack */
+        unsigned short list[2][kPoolSlots];      /* two rings: first in, first out */
+        int lock;
+        int n_free;
+        int head[2], count[2];
+};
+
+__device__ __forceinline__ int lane_rank(ull mask)
+{
+        return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
 /* Two-phase launches.  Steps per ray are heavy-tailed (C2: median 163, max
  * 11 327) and a ray's samples are sequential, so a launch lasts as long as its
  * longest ray.  Phase A therefore PARKS any ray that reaches `park_after` steps
@@ -2021,6 +2098,7 @@ struct PhaseIO {
         double * ds_mark;       /* A: a ray's step length at step mark_at */
         int mark_at;
         float long_if;          /* A: to the front, if expected to take more further steps than this */
+        int pool;               /* B: the waves of a block exchange rays through LDS (RayPool) */
 };
 
 /* CROSS: a ray whose step crossed a boundary is not bisected here (ST_BISECT
@@ -2031,7 +2109,7 @@ struct PhaseIO {
  * its id, the tentative length and the medium the sample found in ph.cross -- and
  * k_cross locates every crossing of the batch afterwards, in full waves.  The
  * lane takes a new ray at once. */
-template <int MODE, bool FAST, bool MODEL, bool PAGED, bool CROSS>
+template <int MODE, bool FAST, bool MODEL, bool PAGED, bool CROSS, bool POOL = false>
 __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
     double * __restrict__ pos, const double * __restrict__ dir, int max_steps,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
@@ -2076,9 +2154,155 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
         int home = -1; /* CAN_FAULT: the tile of the ray's last sample (see Sample.slot) */
         ull my_rays = 0, my_steps = 0, my_samples = 0, my_capped = 0;
 
+        /* ---- the block's pool of rays (see RayPool) ---- */
+        constexpr bool POOLED = POOL && (TRACE_POOL != 0) && FAST && MODEL && CROSS && !PAGED &&
+            ((MODE == TAMD_MODE_ONE_MAP) || (MODE == TAMD_MODE_ONE_STACK));
+        typedef __attribute__((address_space(3))) RayPool * lds_pool_t;
+        lds_pool_t P = nullptr;
+        bool pooled = false;   /* block-uniform */
+        bool stopped_ = false; /* this lane's ray left a group of lean steps: it needs a general iteration */
+        int role = ROLE_AS_IS; /* wave-uniform */
+        bool pool_empty = true; /* wave-uniform: nothing was left in the pool at the last look */
+        int pool_free = kPoolSlots;
+        int idle_trips = 0;
+#ifdef TRACE_POOL_STATS
+        unsigned long long pstat_[24] = { 0 };
+#endif
+        if constexpr (POOLED) {
+                __shared__ RayPool pool_;
+                P = (lds_pool_t)&pool_;
+                pooled = (ph.pool > 0) && ((MODE == TAMD_MODE_ONE_MAP) || ctx.stack.regular);
+                if (pooled) {
+                        for (int t = threadIdx.x; t < kPoolSlots; t += 256) P->free_slot[t] = (unsigned short)t;
+                        if (threadIdx.x == 0) {
+                                P->lock = 0, P->n_free = kPoolSlots;
+                                P->head[0] = P->head[1] = 0, P->count[0] = P->count[1] = 0;
+                        }
+                        __syncthreads();
+                }
+        }
+        /* One look at the pool: the wave takes its role and rays change places.  Whole wave. */
+        auto pool_exchange = [&]() {
+                if constexpr (POOLED) {
+                        const bool has = (ray >= 0);
+                        const bool ready = has & !stopped_ & (state == ST_STEP) & lined_ & line.valid &
+                            (cell.id != ~0u) & (count + kCreepUnroll < max_steps);
+                        const bool waits = has & !ready;
+                        const int r_own = __popcll(__ballot(ready)), s_own = __popcll(__ballot(waits));
+                        const int e_own = 64 - r_own - s_own;
+                        const unsigned long long t_in = PSTAT_CLOCK();
+                        (void)t_in;
+                        /* the lock: one lane asks, the wave waits */
+                        if ((threadIdx.x & 63) == 0) {
+                                /* (bounded: a kernel must always end, whatever went wrong) */
+                                int expected = 0;
+                                for (int spin = 0; (spin < (1 << 22)) &&
+                                     !__hip_atomic_compare_exchange_strong(&P->lock, &expected, 1, __ATOMIC_ACQUIRE,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); spin++) {
+                                        expected = 0;
+                                        __builtin_amdgcn_s_sleep(2);
+                                }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        PSTAT(16, PSTAT_CLOCK() - t_in);
+                        const int F = __builtin_amdgcn_readfirstlane(P->n_free);
+                        const int R = __builtin_amdgcn_readfirstlane(P->count[POOL_READY]);
+                        const int S = __builtin_amdgcn_readfirstlane(P->count[POOL_SERVICE]);
+                        const int head_r = __builtin_amdgcn_readfirstlane(P->head[POOL_READY]);
+                        const int head_s = __builtin_amdgcn_readfirstlane(P->head[POOL_SERVICE]);
+                        /* what each role would have to work on */
+                        const int lean_out = min(s_own, F), lean_in = min(R, e_own + lean_out);
+                        const int lean_n = r_own + lean_in;
+                        const int serv_out = min(r_own, F), serv_in = min(S, e_own + serv_out);
+                        const int serv_n = s_own + serv_in;
+                        if (exhausted && (r_own + s_own + R + S < 64))
+                                role = ROLE_AS_IS;
+                        else if ((lean_n >= kPoolLeanMin) || (exhausted && (lean_n > serv_n)))
+                                role = ROLE_LEAN;
+                        else
+                                role = ROLE_SERVICE;
+                        /* who goes */
+                        const bool goes = (role == ROLE_LEAN) ? waits : ((role == ROLE_SERVICE) ? ready : false);
+                        const int n_out = (role == ROLE_LEAN) ? lean_out : ((role == ROLE_SERVICE) ? serv_out : 0);
+                        const int out_kind = (role == ROLE_LEAN) ? POOL_SERVICE : POOL_READY;
+                        const int out_rank = lane_rank(__ballot(goes));
+                        const bool push = goes & (out_rank < n_out);
+                        int out_slot = 0;
+                        if (push) out_slot = P->free_slot[F - 1 - out_rank];
+                        /* who comes: into the lanes that are or become free -- ready rays for a
+                         * lean wave, waiting ones for a serving wave, either kind at the end */
+                        const bool free_lane = !has | push;
+                        const int in_rank = lane_rank(__ballot(free_lane));
+                        int n_in_r = 0, n_in_s = 0;
+                        if (role == ROLE_LEAN) n_in_r = lean_in;
+                        if (role == ROLE_SERVICE) n_in_s = serv_in;
+                        if (role == ROLE_AS_IS) n_in_r = min(R, e_own), n_in_s = min(S, e_own - n_in_r);
+                        const bool pull_r = free_lane & (in_rank < n_in_r);
+                        const bool pull_s = free_lane & !pull_r & (in_rank < n_in_r + n_in_s);
+                        int in_slot = 0;
+                        if (pull_r) in_slot = P->list[POOL_READY][(head_r + in_rank) % kPoolSlots];
+                        if (pull_s) in_slot = P->list[POOL_SERVICE][(head_s + in_rank - n_in_r) % kPoolSlots];
+                        if (push) {
+                                const int q = out_slot;
+                                P->d[0][q] = bx, P->d[1][q] = by, P->d[2][q] = bz;
+                                P->d[3][q] = dx, P->d[4][q] = dy, P->d[5][q] = dz;
+                                P->d[6][q] = len, P->d[7][q] = ds, P->d[8][q] = line.s;
+                                P->d[9][q] = line.lat[0], P->d[10][q] = line.lat[1], P->d[11][q] = line.lat[2], P->d[12][q] = line.lat[3];
+                                P->d[13][q] = line.lon[0], P->d[14][q] = line.lon[1], P->d[15][q] = line.lon[2], P->d[16][q] = line.lon[3];
+                                P->d[17][q] = line.alt[0], P->d[18][q] = line.alt[1], P->d[19][q] = line.alt[2], P->d[20][q] = line.alt[3];
+                                P->d[21][q] = line.k4, P->d[22][q] = line.tau;
+                                P->i[0][q] = (int)ray, P->i[1][q] = count, P->i[2][q] = m, P->i[3][q] = k;
+                                P->i[4][q] = state | (lined_ ? 4 : 0) | (line.valid ? 8 : 0) | (stopped_ ? 16 : 0);
+                                P->i[5][q] = (int)cell.id, P->i[6][q] = (int)cell.lo, P->i[7][q] = (int)cell.hi;
+                                /* the steps a ray took are counted by the wave that took them */
+                                my_steps += (ull)(count - count0);
+                                ray = -1;
+                        }
+                        if (pull_r | pull_s) {
+                                const int q = in_slot;
+                                bx = P->d[0][q], by = P->d[1][q], bz = P->d[2][q];
+                                dx = P->d[3][q], dy = P->d[4][q], dz = P->d[5][q];
+                                len = P->d[6][q], ds = P->d[7][q], line.s = P->d[8][q];
+                                line.lat[0] = P->d[9][q], line.lat[1] = P->d[10][q], line.lat[2] = P->d[11][q], line.lat[3] = P->d[12][q];
+                                line.lon[0] = P->d[13][q], line.lon[1] = P->d[14][q], line.lon[2] = P->d[15][q], line.lon[3] = P->d[16][q];
+                                line.alt[0] = P->d[17][q], line.alt[1] = P->d[18][q], line.alt[2] = P->d[19][q], line.alt[3] = P->d[20][q];
+                                line.k4 = P->d[21][q], line.tau = P->d[22][q];
+                                ray = P->i[0][q], count = P->i[1][q], m = P->i[2][q], k = P->i[3][q];
+                                count0 = count;
+                                const int bits = P->i[4][q];
+                                state = bits & 3, lined_ = (bits & 4) != 0, line.valid = (bits & 8) != 0, stopped_ = (bits & 16) != 0;
+                                cell.id = (unsigned)P->i[5][q], cell.lo = (unsigned)P->i[6][q], cell.hi = (unsigned)P->i[7][q];
+                        }
+                        /* the lists: slots that were read are free again, the ones written are listed */
+                        const int n_in = n_in_r + n_in_s;
+                        if (pull_r | pull_s) P->free_slot[F - n_out + in_rank] = (unsigned short)in_slot;
+                        /* (a ring's tail is where it was: what came out of it came from its head) */
+                        const int tail = ((out_kind == POOL_READY) ? head_r + R : head_s + S) + out_rank;
+                        if (push) P->list[out_kind][tail % kPoolSlots] = (unsigned short)out_slot;
+                        if ((threadIdx.x & 63) == 0) {
+                                P->n_free = F - n_out + n_in;
+                                P->head[POOL_READY] = (head_r + n_in_r) % kPoolSlots;
+                                P->head[POOL_SERVICE] = (head_s + n_in_s) % kPoolSlots;
+                                P->count[POOL_READY] = R - n_in_r + ((out_kind == POOL_READY) ? n_out : 0);
+                                P->count[POOL_SERVICE] = S - n_in_s + ((out_kind == POOL_SERVICE) ? n_out : 0);
+                        }
+                        pool_empty = (R - n_in_r + S - n_in_s + n_out) == 0;
+                        pool_free = F - n_out + n_in;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if ((threadIdx.x & 63) == 0)
+                                __hip_atomic_store(&P->lock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        PSTAT(0, 1), PSTAT((role == ROLE_AS_IS) ? 3 : role, 1), PSTAT(4, PSTAT_CLOCK() - t_in), PSTAT(13, n_out), PSTAT(14, n_in);
+                        PSTAT(17, r_own), PSTAT(18, s_own), PSTAT(19, R), PSTAT(20, S);
+                }
+        };
+
         for (;;) {
+                if (POOLED && pooled) pool_exchange();
                 /* ---- refill idle lanes from the queue ---- */
                 for (;;) {
+                        /* (pooled: a lean wave takes no new ray -- it would wait for a general
+                         * iteration -- and a block whose pool is nearly full has rays enough) */
+                        if (POOLED && pooled && ((role == ROLE_LEAN) || (pool_free < kPoolRefillFree))) break;
                         const bool need = (ray < 0) && !dead;
                         const ull mask = __ballot(need);
                         if (mask == 0) break;
@@ -2118,6 +2342,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 if (ph.ids != nullptr)
                                         ray = ph.ids[(ray < n_front) ? ray : capacity - 1 - (ray - n_front)];
                                 if (MODEL) line.valid = false, line.s = 0., line.tau = kLineTau0;
+                                stopped_ = false;
                                 bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
                                 dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
                                 len = 0., count = 0, state = ST_INIT;
@@ -2138,7 +2363,18 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                         }
                         pool_next += min((long)__popcll(mask), avail);
                 }
-                if (__ballot(ray >= 0) == 0) break;
+                if (__ballot(ray >= 0) == 0) {
+                        if (!(POOLED && pooled)) break;
+                        /* pooled: the wave leaves when the queue is dry and the pool was empty at
+                         * its last look; else it looks again (a kernel must always end: a wave that
+                         * finds nothing a million times over leaves too -- its rays, if any were
+                         * left, are then missing from the totals, which the callers check) */
+                        if ((exhausted && pool_empty) || (++idle_trips > 1000000)) break;
+                        if (role == ROLE_LEAN) role = ROLE_SERVICE; /* (cannot be: a lean wave has rays) */
+                        __builtin_amdgcn_s_sleep(8);
+                        continue;
+                }
+                idle_trips = 0;
                 /* ---- creep loop (phase B, sparse waves) ---------------------------
                  * What is left at the end of a launch is a handful of rays
                  * skimming the ground with ~0.5 m steps for thousands of steps.
@@ -2212,7 +2448,8 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                 if (creep_wait > 0) creep_wait--;
                 if (MODEL &&
                     ((MODE == TAMD_MODE_ONE_MAP) || ((MODE == TAMD_MODE_ONE_STACK) && ctx.stack.regular)) &&
-                    (sparse || ((ph.dense_go > 0) && (creep_wait == 0)))) {
+                    (sparse || ((ph.dense_go > 0) && (creep_wait == 0)) || (POOLED && (role == ROLE_LEAN))) &&
+                    !(POOLED && (role == ROLE_SERVICE))) {
                         /* one map: the grid.  A regular stack: the tile the cached cell is
                          * in -- the shared tile shape at that tile's origin, computed as
                          * f_stack_elevation computes it; a point `interior` to it (same
@@ -2285,12 +2522,15 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                          * between them: that chain is what a step of a lone wave waits for. */
                         const double sgn = (m == 0) ? -1. : 1.; /* a lane's medium does not change in here */
                         const int count_in = count;
+                        const unsigned long long t_lean = PSTAT_CLOCK();
+                        (void)t_lean;
                         for (int it = 0; it < 4096; it++) {
                                 /* no short-circuits below: every lane computes
                                  * everything (garbage is harmless, nothing is
                                  * committed on failure) and the tests are AND-ed */
                                 bool going = (ray >= 0) & (state == ST_STEP) & lined_ & line.valid & cached &
                                     (count + kCreepUnroll < max_steps);
+                                PSTAT(5, 1), PSTAT(7, __popcll(__ballot(going)));
 #pragma unroll
                                 for (int u = 0; u < kCreepUnroll; u++) {
                                         const double sl = line.s + ds;
@@ -2341,6 +2581,8 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 const bool stopped = (ray >= 0) & !going;
                                 const int n_stopped = __popcll(__ballot(stopped));
                                 if (n_stopped == 0) continue;
+                                if (POOLED && pooled) stopped_ = stopped;
+                                if (POOLED && (role == ROLE_LEAN)) break; /* the pool takes them: see RayPool */
                                 if (!sparse) {
                                         /* a busy wave: the lanes that stopped wait while
                                          * enough of the others step on (a group of lean
@@ -2356,7 +2598,9 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 break;
                         }
                         my_samples += (ull)(count - count_in); /* a lean step is a sample */
+                        PSTAT(11, PSTAT_CLOCK() - t_lean), PSTAT(6, wave_sum((ull)(count - count_in)));
                 }
+                if (POOLED && (role == ROLE_LEAN)) continue; /* back to the pool: no general iteration */
 
                 /* `drain`: once the queue is dry a wave of phase A hands its rays over
                  * as they stand (between two steps) instead of stepping its last few
@@ -2366,6 +2610,9 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                 const bool drain = !MODEL && (ph.park_after > 0) && exhausted && (ray >= 0) &&
                     (state == ST_STEP) && (__popcll(__ballot(ray >= 0)) <= ph.drain_lanes);
                 bool park = drain;
+                const unsigned long long t_gen = PSTAT_CLOCK();
+                (void)t_gen;
+                PSTAT(8, 1), PSTAT(9, __popcll(__ballot(ray >= 0)));
                 TileFault fault = { -1, 0, 0 }; /* the tiles to page in, if any */
                 double fx = 0, fy = 0, fz = 0; /* where the ray goes back to, then */
                 bool defer = false; /* MODEL: the lane waits for a closed form (see below) */
@@ -2405,6 +2652,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                         defer = relay & !now;
                                         relay = relay & now;
                                 }
+                                PSTAT(10, __popcll(__ballot(relay)));
                                 if (relay) {
                                         f_line_relay<MODE>(v, ctx, qx, qy, qz, dx, dy, dz, line, s, cache);
                                         line.s = -t;
@@ -2429,6 +2677,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 fx = bx - dx * back, fy = by - dy * back, fz = bz - dz * back;
                         }
 
+                        if (POOLED) stopped_ = defer;
                         /* ---- bookkeeping ----
                          * STEP and BISECT are handled together, as selects rather
                          * than branches: in a busy wave every case is present in
@@ -2551,6 +2800,7 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 ray = -1;
                         }
                 }
+                PSTAT(12, PSTAT_CLOCK() - t_gen);
                 /* ---- park over-long rays (phase A; whole wave takes part) ---- */
                 if (!MODEL && (ph.ds_mark != nullptr) && (ray >= 0) && (state == ST_STEP) &&
                     (count == ph.mark_at))
@@ -2649,6 +2899,11 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                 }
         }
 
+#ifdef TRACE_POOL_STATS
+        if (MODEL && ((threadIdx.x & 63) == 0))
+                for (int i = 0; i < 24; i++)
+                        if (pstat_[i]) atomicAdd(&g_pool_stats[i], pstat_[i]);
+#endif
         block_tally(stats, my_rays, my_steps, my_samples, my_capped);
 }
 
@@ -2669,7 +2924,7 @@ constexpr int trace_waves()
                (FAST && !MODEL && !PAGED && (MODE != TAMD_MODE_GENERIC)) ? TRACE_A_WAVES : 1;
 }
 
-template <int MODE, bool FAST, bool MODEL, bool PAGED, bool CROSS>
+template <int MODE, bool FAST, bool MODEL, bool PAGED, bool CROSS, bool POOL = false>
 __global__ void __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(trace_waves<MODE, FAST, MODEL, PAGED>())))
 k_trace(tamd_view v, long n,
@@ -2677,7 +2932,7 @@ k_trace(tamd_view v, long n,
     int * __restrict__ index, double * __restrict__ length, int * __restrict__ n_steps,
     int flags, PhaseIO ph, ull * __restrict__ stats, ull * __restrict__ queue)
 {
-        trace_body<MODE, FAST, MODEL, PAGED, CROSS>(v, n, pos, dir, max_steps, index, length, n_steps, flags,
+        trace_body<MODE, FAST, MODEL, PAGED, CROSS, POOL>(v, n, pos, dir, max_steps, index, length, n_steps, flags,
             ph, stats, queue);
 }
 
@@ -3070,6 +3325,18 @@ extern "C" int tamd_dev_count(void)
         if (hipGetDeviceCount(&count) != hipSuccess) return 0;
         return count;
 }
+
+#ifdef TRACE_POOL_STATS
+extern "C" int tamd_dev_pool_stats(unsigned long long * out, int reset)
+{
+        HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pool_stats), sizeof(g_pool_stats)));
+        if (reset) {
+                static unsigned long long zero[32];
+                HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pool_stats), zero, sizeof(zero)));
+        }
+        return 0;
+}
+#endif
 
 extern "C" int tamd_dev_select(int device)
 {
@@ -3502,12 +3769,12 @@ extern "C" void tamd_dev_in_flight_set(int batches) { g_ctx.in_flight = (batches
 extern "C" int tamd_dev_in_flight_get(void) { return g_ctx.in_flight; }
 extern "C" int tamd_dev_math_get(void) { return g_ctx.math_strict; }
 
-template <int MODE, bool FAST, bool MODEL, bool PAGED, bool CROSS>
+template <int MODE, bool FAST, bool MODEL, bool PAGED, bool CROSS, bool POOL = false>
 static int launch_trace_(struct tamd_view view, long n, bool n_on_device, double * pos,
     const double * dir, int max_steps, int * index, double * length, int * n_steps,
     int flags, PhaseIO ph, ull * stats, ull * queue)
 {
-        const void * kernel = (const void *)k_trace<MODE, FAST, MODEL, PAGED, CROSS>;
+        const void * kernel = (const void *)k_trace<MODE, FAST, MODEL, PAGED, CROSS, POOL>;
         long blocks = (long)g_cus * trace_blocks_per_cu(kernel);
         const long useful = (n + 255) / 256;
         if (!n_on_device && (blocks > useful)) blocks = useful;
@@ -3526,7 +3793,7 @@ static int launch_trace_(struct tamd_view view, long n, bool n_on_device, double
                 if (wide < (long)g_cus) wide = (long)g_cus;
                 if (blocks > wide) blocks = wide;
         }
-        hipLaunchKernelGGL((k_trace<MODE, FAST, MODEL, PAGED, CROSS>), dim3((unsigned)blocks), dim3(256),
+        hipLaunchKernelGGL((k_trace<MODE, FAST, MODEL, PAGED, CROSS, POOL>), dim3((unsigned)blocks), dim3(256),
             0, g_stream, view, n, pos, dir, max_steps, index, length, n_steps, flags, ph, stats,
             queue);
         LAUNCH_CHECK("k_trace");
@@ -3552,6 +3819,10 @@ static int launch_trace(struct tamd_view view, long n, bool n_on_device, double 
                 if (cross) return launch_trace_<MODE, FAST, MODEL, CAN_PAGE, true>(TRACE_ARGS);
                 if constexpr (!MODEL) return launch_trace_<MODE, FAST, MODEL, CAN_PAGE, false>(TRACE_ARGS);
         }
+        /* the lined pass of one map / one stack with its rays pooled per block (RayPool): an
+         * instance of its own, so that the one without is what it was */
+        if constexpr (FAST && MODEL && (MODE != TAMD_MODE_GENERIC))
+                if (cross && (ph.pool > 0)) return launch_trace_<MODE, FAST, MODEL, false, true, true>(TRACE_ARGS);
         if (cross) return launch_trace_<MODE, FAST, MODEL, false, true>(TRACE_ARGS);
         if constexpr (!MODEL) return launch_trace_<MODE, FAST, MODEL, false, false>(TRACE_ARGS);
         return 1;
@@ -3628,6 +3899,20 @@ static int sort_long_if(void)
         if (value < 0) value = env_int("TURTLE_AMD_SORT_LONG", 120);
         return value;
 }
+/* Do the lined pass's waves exchange rays through LDS (RayPool)?  The same bits either way
+ * (test_ray_pool_changes_no_bit); what it is worth, measured (round 4, one MI355X, each alone):
+ * one map, 12.5 M rays (C4) 27.0 -> 26.0-26.4 ms; one map, 1 M rays (C2) 3.37 -> 3.55-3.72 ms
+ * (a batch that small is as long as its longest rays' own chains, and a ray moves slower in a
+ * wave that is kept full); a stack, 10 M rays (C3) 25.4 -> 31.7-33.9 ms (the stack's pooled
+ * kernel spills 312 bytes a lane at three waves a SIMD).  So: one map, from 4 M rays on.
+ * TURTLE_AMD_POOL=0 / 1: never / wherever the kernel exists. */
+static int pool_on(int mode, long n)
+{
+        static int value = -2;
+        if (value == -2) value = env_int("TURTLE_AMD_POOL", -1);
+        if (value >= 0) return value;
+        return (mode == TAMD_MODE_ONE_MAP) && (n >= 4000000);
+}
 static int drain_lanes(void)
 {
         static int value = -1;
@@ -3694,6 +3979,7 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
                 kChunk, creep_lanes(n), dense_go(), cross };
         PhaseIO b = { parked, queue + 2 * kQ, nullptr, nullptr, 0, 1, pg, 0, park, kChunk,
                 creep_lanes(n), dense_go(), cross };
+        b.pool = pool_on(MODE, n);
         const int long_if = sort_long_if();
         if (!again && (long_if > 0)) {
                 /* (a later round of a paged trace takes rays at any step count: unsorted) */
