@@ -1,6 +1,7 @@
 #!/bin/bash
 # Evidence for profiles/: bench line, rocprofv3 kernel stats, PMC passes.
-# usage (on the GPU box): bash scripts/profile_round.sh <tag> [workload: c2 | c3 | c5] [rays] [passes: "A B C D" | none]
+# usage (on the GPU box): bash scripts/profile_round.sh <tag> [workload: c2 | c3 | c4 | c5 | c5_step_n] [rays] [passes: "A B C D" | none]
+# MATH=strict: the reference's arithmetic (the bench leg c2!strict)
 # Every pass stays within the per-block counter slots of gfx950 (SQ 8, TCC 4: FETCH_SIZE
 # takes 3, WRITE_SIZE 2; GRBM 2) and asks for nothing of the TA block.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -8,8 +9,14 @@ tag=${1:-rXX}
 wl=${2:-c2}
 rays=${3:-0}
 passes=${4:-A B C D}
+math=${MATH:-fast}
+export TURTLE_AMD_MATH=$math
 WL="--workload $wl --rays $rays --also none --in-flight 1"   # one batch at a time: the kernels alone on the GPU
 kernel="k_trace|k_cross"; [ "$wl" = c5 ] && kernel=k_walk
+if [ "$wl" = c5_step_n ]; then
+  # the walk through turtle_stepper_step_n, the caller's directions: two kernels a generation
+  WL="--workload c5 --step-n 64 --rays $rays --also none --in-flight 1"; kernel="k_step|k_bisect"
+fi
 out=gpurun_out/$tag
 mkdir -p $out
 timeout -k 10 600 python3 bench.py $WL > $out/bench.json 2> $out/bench.err
@@ -32,7 +39,7 @@ run E TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES
 if [ "$passes" != none ]; then
   python3 scripts/pmc_summary.py $out "$kernel" > $out/pmc_summary.txt
   nrays=$(python3 -c "import json; print(json.loads(open('$out/bench.json').read().strip().splitlines()[-1])['config']['rays_per_gpu'])")
-  python3 scripts/pmc_to_json.py $out/pmc_summary.txt $wl $nrays fast > $out/pmc.json
+  python3 scripts/pmc_to_json.py $out/pmc_summary.txt $wl $nrays $math > $out/pmc.json
   cat $out/pmc_summary.txt
 fi
 rm -rf $out/stats $out/pmc_A $out/pmc_B $out/pmc_C $out/pmc_D $out/pmc_E

@@ -440,3 +440,45 @@ def test_threads_share_a_map_and_a_locked_stack(tmp_path):
     assert shared.resident <= 2 and not mutex.locked()
     shared.destroy()
     tile.destroy()
+
+
+def test_a_tile_that_comes_back_is_not_read_again_unless_its_file_changed(tmp_path):
+    """Round 4: the page-locked buffers tiles are read into keep the nodes of the tile they last
+    held, and a tile that comes back while they are there is copied from the buffer instead of
+    read from its file (a batch over a stack smaller than its ground goes to and fro between two
+    sets of tiles).  Same answers as a stack that holds everything -- host nodes (turtle_map_node
+    of the scalar path) and HBM copy alike -- and a file that was rewritten meanwhile is READ."""
+    import time
+    d = str(tmp_path / "grid")
+    for la, lo in ((45, 3), (45, 4), (46, 3)):
+        synth.write_hgt(d, la, lo, N_TILE)
+    full, small = TA.Stack(d, 0), TA.Stack(d, 1)
+    full.load()
+    rng = np.random.default_rng(3)
+    boxes = {"a": (45.0, 3.0), "b": (45.0, 4.0), "c": (46.0, 3.0)}
+    pts = {k: (rng.uniform(la + 0.01, la + 0.99, 2000), rng.uniform(lo + 0.01, lo + 0.99, 2000))
+           for k, (la, lo) in boxes.items()}
+    # to and fro: every tile is dropped and comes back several times
+    for k in "abcabacbca":
+        z0, in0 = full.elevation(*pts[k])
+        z1, in1 = small.elevation(*pts[k])
+        assert in0.all() and np.array_equal(in0, in1) and np.array_equal(z0, z1), k
+        assert small.resident == 1
+        # the host's copy of a tile that came from a buffer is the file's too (scalar path)
+        TA.set_scalar("host")
+        try:
+            zs, _ = small.elevation_scalar(float(pts[k][0][0]), float(pts[k][1][0]))
+        finally:
+            TA.set_scalar("device")
+        assert zs == z0[0]
+    # tile a's file is rewritten while tile b is the one in memory: a is read again
+    z_b, _ = small.elevation(*pts["b"])
+    nodes = synth.srtm_like_nodes(45, 3, N_TILE)
+    time.sleep(0.02)
+    with open(os.path.join(d, synth.hgt_name(45, 3, N_TILE)), "wb") as f:
+        f.write(synth.hgt_bytes((nodes + 100).astype(nodes.dtype)))
+    z_old, _ = full.elevation(*pts["a"])
+    z_new, inside = small.elevation(*pts["a"])
+    assert inside.all() and np.allclose(z_new, z_old + 100.0, atol=1e-9)
+    full.destroy()
+    small.destroy()

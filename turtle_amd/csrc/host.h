@@ -50,7 +50,11 @@ struct turtle_map {
         struct turtle_projection projection; /* type < 0: geodetic */
         struct turtle_stack * stack; /* owner, or NULL */
 
-        uint16_t * nodes;     /* host copy: native endian, rows south->north */
+        uint16_t * nodes;     /* host copy: native endian, rows south->north -- or NULL for a
+                               * tile that came back from a staging buffer (stage_tile): the
+                               * kernels read the HBM copy; the host reads `lazy_path` when it
+                               * first needs the nodes (tamd_map_host_nodes) */
+        const char * lazy_path; /* the tile's file (the stack's string), or NULL */
         void * d_nodes[TAMD_MAX_DEVICES]; /* HBM copies (in blocks: internal.h), one per device */
         unsigned d_fresh;     /* bit d: the copy on device d is current */
         /* a tile of a stack, just read: its nodes in the HBM layout, in one of the stack's
@@ -80,6 +84,9 @@ void tamd_geometry_write_end(void);
  * their devices has run */
 void tamd_map_release(struct turtle_map * map);
 
+/* the host copy of the nodes is there (a tile that came without: read now); 0, or an
+ * enum turtle_return */
+int tamd_map_host_nodes(struct turtle_map * map);
 /* fills the decode parameters of `grid` and makes the HBM copy current */
 int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid);
 enum turtle_return tamd_map_load_(struct turtle_map ** map, const char * path,
@@ -133,9 +140,21 @@ struct turtle_stack {
         uint16_t * stage[TAMD_STAGE_SLOTS];
         int stage_device[TAMD_STAGE_SLOTS];
         size_t stage_bytes;
+        /* A buffer still holds a tile's nodes, laid out for HBM, after its upload -- and
+         * after the tile has left the stack: a tile that COMES BACK while they are there
+         * (a batch over a stack smaller than its ground goes to and fro between two sets
+         * of tiles, round after round) is not read from its file again: its nodes are
+         * copied back from the buffer and uploaded.  `stage_tile`: the directory slot of
+         * that tile (-1: none), with the size and time stamp its file had when it was read
+         * (a file that has changed is read again); `stage_stamp`: when the buffer was last
+         * filled or found -- the least recent one is overwritten first.  No memory beyond
+         * the buffers themselves. */
+        int stage_tile[TAMD_STAGE_SLOTS];
+        long long stage_file_size[TAMD_STAGE_SLOTS], stage_file_time[TAMD_STAGE_SLOTS];
+        unsigned long stage_stamp[TAMD_STAGE_SLOTS];
         /* HBM buffers of tiles that went, kept for the tiles that come (one size: the tiles of
          * a stack have one shape): hipMalloc / hipFree wait for the device */
-#define TAMD_SPARE_HBM 16
+#define TAMD_SPARE_HBM 32
         void * spare[TAMD_MAX_DEVICES][TAMD_SPARE_HBM];
         int n_spare[TAMD_MAX_DEVICES];
         size_t spare_bytes;
@@ -146,6 +165,8 @@ struct tamd_tile_job {
         const char * path;
         uint16_t * staged;        /* in: a staging buffer of `staged_bytes`, or NULL */
         size_t staged_bytes;
+        int cached;               /* in: `staged` holds this tile's nodes already (see stage_tile):
+                                   * the file's header is read, its nodes are not */
         struct turtle_map * map;  /* out: the tile (calloc'ed; nodes malloc'ed), or NULL */
         int rc;                   /* out: an enum turtle_return */
 };
@@ -175,8 +196,14 @@ int tamd_stack_preload(struct turtle_stack * stack, char * message, size_t size)
  * item of the list: at most a 3 x 3 neighbourhood and one more) come in without
  * fail, whatever has to go.  Returns the number of tiles loaded, or minus an
  * enum turtle_return with `message` set. */
+/* `few`: the round left only a handful of items waiting (TAMD_PAGING_FEW): their tiles come in
+ * beyond the stack's size, by up to that size again or TAMD_PAGING_SLACK tiles, whichever is less */
+/* (diagnostics, TURTLE_AMD_PAGING_TRACE: tiles that came from a staging buffer, in all) */
+extern unsigned long tamd_stack_buffer_hits;
+#define TAMD_PAGING_FEW 4096
+#define TAMD_PAGING_SLACK 8
 int tamd_stack_page_in(struct turtle_stack * stack, const unsigned * wanted,
-    const unsigned * wanted_first, int first_bit, char * message, size_t size);
+    const unsigned * wanted_first, int first_bit, int few, char * message, size_t size);
 
 struct turtle_client {
         struct turtle_stack * stack;

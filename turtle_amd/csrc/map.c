@@ -297,6 +297,35 @@ void turtle_map_meta(const struct turtle_map * map, struct turtle_map_info * inf
         if (projection != NULL) *projection = turtle_projection_name(&map->projection);
 }
 
+/* A tile that came back from a staging buffer has no host copy of its nodes (host.h): the
+ * first reader on the host -- the scalar path, an upload to a second device -- reads the file,
+ * under the geometry lock (readers on the host hold the geometry in use: nobody frees the tile) */
+int tamd_map_host_nodes(struct turtle_map * map)
+{
+        if (__atomic_load_n(&map->nodes, __ATOMIC_ACQUIRE) != NULL) return TURTLE_RETURN_SUCCESS;
+        int rc = TURTLE_RETURN_SUCCESS;
+        tamd_geometry_lock();
+        if (map->nodes == NULL) {
+                int (*probe)(const char *, struct turtle_map *);
+                int (*read)(const char *, struct turtle_map *);
+                struct turtle_map copy = *map;
+                copy.nodes = NULL;
+                if ((map->lazy_path == NULL) || !tamd_codec_for(map->lazy_path, &probe, &read))
+                        rc = TURTLE_RETURN_PATH_ERROR;
+                else {
+                        copy.nodes = malloc((size_t)map->nx * map->ny * sizeof(*copy.nodes));
+                        rc = (copy.nodes == NULL) ? TURTLE_RETURN_MEMORY_ERROR : read(map->lazy_path, &copy);
+                        if (rc > N_TURTLE_RETURNS) rc = TURTLE_RETURN_BAD_FORMAT;
+                }
+                if (rc == TURTLE_RETURN_SUCCESS)
+                        __atomic_store_n(&map->nodes, copy.nodes, __ATOMIC_RELEASE);
+                else
+                        free(copy.nodes);
+        }
+        tamd_geometry_unlock();
+        return rc;
+}
+
 int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
 {
         /* HBM layout: blocks of TAMD_BLOCK x TAMD_BLOCK nodes (internal.h); one copy
@@ -334,7 +363,7 @@ int tamd_map_sync(struct turtle_map * map, struct tamd_grid * grid)
                          * (stage_acquire), not now */
                         tamd_stack_staged_done(map, (queued && failed) ? device : -1);
                 } else {
-                        uint16_t * blocked = malloc(bytes);
+                        uint16_t * blocked = (tamd_map_host_nodes(map) == TURTLE_RETURN_SUCCESS) ? malloc(bytes) : NULL;
                         if (blocked == NULL) {
                                 tamd_geometry_unlock();
                                 return 1;

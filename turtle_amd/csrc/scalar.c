@@ -180,6 +180,8 @@ static double h_node(const struct turtle_map * m, int ix, int iy)
 int tamd_h_map_elevation(const struct turtle_map * m, double x, double y, double * z)
 {
         if (isnan(x) || isnan(y)) return 0; /* [ref map.c:233-240] */
+        /* (a tile that came back from a staging buffer: its nodes are read now) */
+        if ((m->nodes == NULL) && (tamd_map_host_nodes((struct turtle_map *)m) != TURTLE_RETURN_SUCCESS)) return 0;
         double hx = (x - m->x0) / m->dx;
         double hy = (y - m->y0) / m->dy;
         if ((hx > m->nx - 1) || (hx < 0) || (hy > m->ny - 1) || (hy < 0)) return 0; /* [ref map.c:247-255] */

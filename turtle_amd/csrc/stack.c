@@ -116,7 +116,7 @@ enum turtle_return turtle_stack_create(struct turtle_stack ** stack,
                 s->stamp = calloc(slots ? slots : 1, sizeof(*s->stamp));
                 s->owner = calloc(slots ? slots : 1, sizeof(*s->owner));
                 int k;
-                for (k = 0; k < TAMD_STAGE_SLOTS; k++) s->stage_device[k] = -1; /* free */
+                for (k = 0; k < TAMD_STAGE_SLOTS; k++) s->stage_device[k] = -1, s->stage_tile[k] = -1; /* free, empty */
         }
         if ((s == NULL) || (s->root == NULL) || (s->path == NULL) || (s->tile == NULL) ||
             (s->stamp == NULL) || (s->owner == NULL)) {
@@ -156,14 +156,48 @@ enum turtle_return turtle_stack_create(struct turtle_stack ** stack,
 
 /* ---- staging buffers and spare HBM buffers (host.h) ------------------------ */
 
-/* a free staging buffer of at least `bytes`: its slot, or -1 (the tile then takes
- * the slow way: laid out and copied when it is first needed) */
-static int stage_acquire(struct turtle_stack * s, size_t bytes)
+unsigned long tamd_stack_buffer_hits = 0;
+
+/* size and time stamp of a file (what a staging buffer's contents are good for) */
+static int file_identity(const char * path, long long * size, long long * time)
+{
+        struct stat st;
+        if (stat(path, &st) != 0) return -1;
+        *size = (long long)st.st_size;
+        *time = (long long)st.st_mtim.tv_sec * 1000000000ll + (long long)st.st_mtim.tv_nsec;
+        return 0;
+}
+
+/* A staging buffer of at least `bytes` for tile `tile` of the directory: its slot, or -1
+ * (the tile then takes the slow way: laid out and copied when it is first needed).
+ * *cached: the buffer holds that tile's nodes already (host.h, stage_tile).  Else a
+ * free buffer: one that holds nothing, or the one whose contents are oldest. */
+static int stage_acquire(struct turtle_stack * s, size_t bytes, int tile, int * cached)
 {
         int k, slot = -1;
+        *cached = 0;
         if ((s->stage_bytes != 0) && (bytes > s->stage_bytes)) return -1; /* (one shape a stack) */
-        for (k = 0; (k < TAMD_STAGE_SLOTS) && (slot < 0); k++)
-                if (s->stage_device[k] == -1) slot = k;
+        long long size = -1, time = -1;
+        const int known = (tile >= 0) && (file_identity(s->path[tile], &size, &time) == 0);
+        for (k = 0; known && (k < TAMD_STAGE_SLOTS); k++) {
+                if ((s->stage_tile[k] != tile) || (s->stage[k] == NULL) || (s->stage_device[k] == -2)) continue;
+                if ((s->stage_file_size[k] != size) || (s->stage_file_time[k] != time)) {
+                        s->stage_tile[k] = -1; /* the file has changed: read it */
+                        continue;
+                }
+                if ((s->stage_device[k] >= 0) && tamd_dev_sync_device(s->stage_device[k])) return -1;
+                s->stage_device[k] = -2;
+                s->stage_stamp[k] = ++s->clock;
+                *cached = 1;
+                tamd_stack_buffer_hits++;
+                return k;
+        }
+        for (k = 0; k < TAMD_STAGE_SLOTS; k++) {
+                if (s->stage_device[k] != -1) continue;
+                if ((slot < 0) || ((s->stage_tile[k] < 0) && (s->stage_tile[slot] >= 0)) ||
+                    (((s->stage_tile[k] < 0) == (s->stage_tile[slot] < 0)) && (s->stage_stamp[k] < s->stage_stamp[slot])))
+                        slot = k;
+        }
         for (k = 0; (k < TAMD_STAGE_SLOTS) && (slot < 0); k++) {
                 if (s->stage_device[k] < 0) continue;
                 /* copied from, on that device: free once it has drained */
@@ -182,6 +216,9 @@ static int stage_acquire(struct turtle_stack * s, size_t bytes)
                 s->stage_bytes = bytes;
         }
         s->stage_device[slot] = -2;
+        s->stage_tile[slot] = known ? tile : -1;
+        s->stage_file_size[slot] = size, s->stage_file_time[slot] = time;
+        s->stage_stamp[slot] = ++s->clock;
         return slot;
 }
 
@@ -191,7 +228,7 @@ static void stage_release_all(struct turtle_stack * s)
         for (k = 0; k < TAMD_STAGE_SLOTS; k++) {
                 if (s->stage_device[k] >= 0) (void)tamd_dev_sync_device(s->stage_device[k]);
                 tamd_dev_host_free(s->stage[k]);
-                s->stage[k] = NULL, s->stage_device[k] = -1;
+                s->stage[k] = NULL, s->stage_device[k] = -1, s->stage_tile[k] = -1;
         }
         s->stage_bytes = 0;
 }
@@ -361,7 +398,7 @@ static int stack_load_tiles(struct turtle_stack * s, const int * which, int coun
                 bytes = tamd_blocked_bytes(meta.nx, meta.ny);
         for (k = 0; k < count; k++) {
                 jobs[k].path = s->path[which[k]];
-                slot[k] = (bytes > 0) ? stage_acquire(s, bytes) : -1;
+                slot[k] = (bytes > 0) ? stage_acquire(s, bytes, which[k], &jobs[k].cached) : -1;
                 jobs[k].staged = (slot[k] >= 0) ? s->stage[slot[k]] : NULL;
                 jobs[k].staged_bytes = s->stage_bytes;
         }
@@ -375,7 +412,7 @@ static int stack_load_tiles(struct turtle_stack * s, const int * which, int coun
         for (k = 0; k < count; k++) {
                 struct turtle_map * m = jobs[k].map;
                 if ((rc != TURTLE_RETURN_SUCCESS) || (m == NULL) || (m->staged == NULL)) {
-                        if (slot[k] >= 0) s->stage_device[slot[k]] = -1;
+                        if (slot[k] >= 0) s->stage_device[slot[k]] = -1, s->stage_tile[slot[k]] = -1;
                         if (m != NULL) m->staged = NULL, m->staged_slot = -1;
                 } else
                         m->staged_slot = slot[k];
@@ -426,19 +463,19 @@ int tamd_stack_preload(struct turtle_stack * s, char * message, size_t size)
 }
 
 static int stack_page_in(struct turtle_stack * s, const unsigned * wanted,
-    const unsigned * wanted_first, int first_bit, char * message, size_t size);
+    const unsigned * wanted_first, int first_bit, int few, char * message, size_t size);
 
 /* Tiles come and go under the stack's lock, when it has one [ref client.c:126-
  * 188: the reference's clients take it around every change of tile] */
 int tamd_stack_page_in(struct turtle_stack * s, const unsigned * wanted,
-    const unsigned * wanted_first, int first_bit, char * message, size_t size)
+    const unsigned * wanted_first, int first_bit, int few, char * message, size_t size)
 {
         if ((s->lock != NULL) && (s->lock() != 0)) {
                 snprintf(message, size, "could not acquire the lock");
                 return -TURTLE_RETURN_LOCK_ERROR;
         }
         tamd_geometry_write_begin();
-        int rc = stack_page_in(s, wanted, wanted_first, first_bit, message, size);
+        int rc = stack_page_in(s, wanted, wanted_first, first_bit, few, message, size);
         tamd_geometry_write_end();
         if ((s->unlock != NULL) && (s->unlock() != 0) && (rc >= 0)) {
                 snprintf(message, size, "could not release the lock");
@@ -448,9 +485,19 @@ int tamd_stack_page_in(struct turtle_stack * s, const unsigned * wanted,
 }
 
 static int stack_page_in(struct turtle_stack * s, const unsigned * wanted,
-    const unsigned * wanted_first, int first_bit, char * message, size_t size)
+    const unsigned * wanted_first, int first_bit, int few, char * message, size_t size)
 {
-        const int n = s->latitude_n * s->longitude_n, budget = tamd_stack_budget(s);
+        const int n = s->latitude_n * s->longitude_n;
+        /* The last few items of a batch (rays that go from tile to tile along the seams: a
+         * few hundred of C3's ten million) would each take a round per tile, and a round costs
+         * its tiles whatever the number of items it serves.  They are served as the reference
+         * serves its clients, who each keep the tile they are on beyond the stack's size [ref
+         * stack.c:433-442: only unpinned tiles go]: their tiles come in beyond the size -- by
+         * at most that size again, or TAMD_PAGING_SLACK tiles -- and the stack is trimmed back
+         * when the call ends (tamd_stack_trim), as it is for the tiles of the first item. */
+        int budget = tamd_stack_budget(s);
+        if (few && (budget < INT_MAX - TAMD_PAGING_SLACK))
+                budget += (budget < TAMD_PAGING_SLACK) ? budget : TAMD_PAGING_SLACK;
         int i, loaded = 0;
 #define FIRST(i) ((wanted_first[((i) + first_bit) >> 5] >> (((i) + first_bit) & 31)) & 1u)
 #define DEMAND(i) (wanted[(size_t)((i) + first_bit) * TAMD_DEMAND_STRIDE])
@@ -690,7 +737,8 @@ static int stack_rounds(struct stack_call * call, char * message, size_t size)
                         break;
                 }
                 if (faulted == 0) break;
-                const int got = tamd_stack_page_in(s, pager.wanted, pager.pinned, 0, message, size);
+                const int got = tamd_stack_page_in(s, pager.wanted, pager.pinned, 0,
+                    faulted <= TAMD_PAGING_FEW, message, size);
                 if (got < 0) {
                         rc = -got;
                         break;

@@ -503,13 +503,13 @@ static int stepper_is_paged(const struct turtle_stepper * s)
 /* the tiles a round wanted, stack by stack (the tile table lists the stacks in
  * the order of s->data): 0 if none could come in, -1 with `code` set on error */
 static int stepper_page_in(struct turtle_stepper * s, const unsigned * wanted,
-    const unsigned * wanted_first, int * code, char * message, size_t size)
+    const unsigned * wanted_first, int few, int * code, char * message, size_t size)
 {
         int i, first = 0, loaded = 0;
         for (i = 0; i < s->n_data; i++) {
                 if (s->data[i].kind != TAMD_STACK) continue;
                 struct turtle_stack * st = s->data[i].stack;
-                const int got = tamd_stack_page_in(st, wanted, wanted_first, first, message, size);
+                const int got = tamd_stack_page_in(st, wanted, wanted_first, first, few, message, size);
                 if (got < 0) {
                         *code = -got;
                         return -1;
@@ -568,14 +568,14 @@ static int stepper_rounds(struct turtle_stepper * stepper, long n, stepper_round
                 }
                 int code = 0;
                 paged = 1;
-                const int got = stepper_page_in(stepper, pager.wanted, pager.pinned, &code,
-                    message, size);
+                const int got = stepper_page_in(stepper, pager.wanted, pager.pinned,
+                    faulted <= TAMD_PAGING_FEW, &code, message, size);
                 if (trace_rounds) {
                         clock_gettime(CLOCK_MONOTONIC, &t3);
-                        fprintf(stderr, "[paging] round %d: tables+launch %.2f ms, kernels %.2f ms, %llu items wait, %d tiles in %.2f ms\n",
+                        fprintf(stderr, "[paging] round %d: tables+launch %.2f ms, kernels %.2f ms, %llu items wait, %d tiles in %.2f ms (%lu from their buffers so far)\n",
                             pager.rounds, 1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec),
                             1e3 * (t2.tv_sec - t1.tv_sec) + 1e-6 * (t2.tv_nsec - t1.tv_nsec), faulted, got,
-                            1e3 * (t3.tv_sec - t2.tv_sec) + 1e-6 * (t3.tv_nsec - t2.tv_nsec));
+                            1e3 * (t3.tv_sec - t2.tv_sec) + 1e-6 * (t3.tv_nsec - t2.tv_nsec), tamd_stack_buffer_hits);
                 }
                 if (got < 0) {
                         rc = code;

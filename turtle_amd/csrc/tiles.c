@@ -85,6 +85,10 @@ static void band_run(struct band * b)
 {
         struct turtle_map * m = b->job->map;
         read_rows_t * rows = rows_reader(b->job->path);
+        if (b->job->cached) { /* (no band is cut for such a tile: nothing to read) */
+                b->rc = TURTLE_RETURN_SUCCESS;
+                return;
+        }
         if (rows != NULL)
                 b->rc = rows(b->job->path, m, b->iy0, b->iy1);
         else {
@@ -139,10 +143,16 @@ void tamd_tiles_decode(struct tamd_tile_job * jobs, int n)
                 }
                 struct turtle_map * m = calloc(1, sizeof(*m));
                 int rc = (m == NULL) ? TURTLE_RETURN_MEMORY_ERROR : probe(job->path, m);
-                if (rc == TURTLE_RETURN_SUCCESS) {
+                /* (a tile whose nodes are in its staging buffer already comes without a host
+                 * copy: 26 MB of fresh pages a tile are what a round would then wait for) */
+                const int cached = job->cached && (job->staged != NULL) && (rc == TURTLE_RETURN_SUCCESS) &&
+                    (tamd_blocked_bytes(m->nx, m->ny) <= job->staged_bytes);
+                job->cached = cached;
+                if ((rc == TURTLE_RETURN_SUCCESS) && !cached) {
                         m->nodes = malloc((size_t)m->nx * m->ny * sizeof(*m->nodes));
                         if (m->nodes == NULL) rc = TURTLE_RETURN_MEMORY_ERROR;
                 }
+                if (cached) m->lazy_path = job->path;
                 if (rc != TURTLE_RETURN_SUCCESS) {
                         if (m != NULL) free(m->nodes);
                         free(m);
@@ -167,7 +177,7 @@ void tamd_tiles_decode(struct tamd_tile_job * jobs, int n)
                 return;
         }
         for (k = 0; k < n; k++) {
-                if (jobs[k].map == NULL) continue;
+                if ((jobs[k].map == NULL) || jobs[k].cached) continue;
                 const int ny = jobs[k].map->ny;
                 int count = (rows_reader(jobs[k].path) != NULL) ? bands_per_tile : 1;
                 /* whole block rows to a band */
