@@ -16,7 +16,7 @@ import terrains as T
 pytestmark = pytest.mark.gpu
 
 N = 1_000_000
-HAND_OVER_MOVED = 4     # rays of creep_probe.py's batches whose step count may move with the hand-over
+HAND_OVER_MOVED = 0     # (logged: none of creep_probe.py's 2 x 40 000 rays changes its step count with the hand-over)
 
 
 @pytest.fixture(scope="module")
