@@ -96,7 +96,8 @@ def measured_traffic(workload, rays, math):
         if d.get("source_hash") != device_source_hash():
             continue
         valu = sum(k.get("SQ_INSTS_VALU", 0.0) for k in d.get("kernels", {}).values())
-        return d.get("traffic_bytes_per_launch"), os.path.basename(path), valu
+        # (passes without FETCH_SIZE / WRITE_SIZE: no figure, not zero)
+        return d.get("traffic_bytes_per_launch") or None, os.path.basename(path), valu or None
     return None, None, None
 
 

@@ -95,6 +95,50 @@ def test_c3_at_full_size():
         terrain.close()
 
 
+def test_c4_at_full_size_with_the_ray_pool():
+    """C4's share of one GPU (12.5 M rays over one 3601^2 tile): the size at which the lined pass's
+    waves exchange rays through LDS (device.hip, RayPool: on for one map from 4 M rays).  A 100 000-ray
+    sample against the CPU restatement, the device's totals, and the whole batch bit for bit against
+    two halves -- each of which is ALSO above the threshold -- and against a quarter, which is below
+    it and runs the kernel without the pool: the pool changes no bit at this size either."""
+    import bench
+    import torch
+    n = 12_500_000
+    env = {"world": 1, "rank": 0}
+    terrain = bench.Terrain(TA, (45, 3, 1, 1), False, env, 0)
+    try:
+        st = terrain.stepper
+        pos0, d = _rays(terrain, n)
+        dev = pos0.device
+
+        def trace(lo, hi):
+            pos = pos0[lo:hi].clone()
+            index = torch.empty((hi - lo, 2), dtype=torch.int32, device=dev)
+            length = torch.empty(hi - lo, dtype=torch.float64, device=dev)
+            nsteps = torch.empty(hi - lo, dtype=torch.int32, device=dev)
+            st.trace_into(pos, d[lo:hi].contiguous(), index, length, nsteps)
+            return dict(position=pos, index=index, length=length, n_steps=nsteps)
+
+        t = trace(0, n)
+        s = st.trace_stats()
+        assert s["rays"] == n and s["steps"] == int(t["n_steps"].sum(dtype=torch.int64)) and s["capped"] == 0
+        m = 100_000
+        ref = terrain.oracle().trace(pos0[:m].cpu().numpy(), d[:m].cpu().numpy(), local_range=0.0,
+                                     threads=bench.host_cores())
+        c = bench.parity_counts(t["index"][:m].cpu().numpy(), t["length"][:m].cpu().numpy(), ref["index"],
+                                ref["length"], t["n_steps"][:m].cpu().numpy(), ref["n_steps"])
+        print("C4, 12.5 M rays (pool on), first 100 000 against the CPU restatement:", c)
+        assert c["medium_mismatch"] == 0 and c["beyond_1e-6"] == 0
+        assert c["step_count_mismatch"] <= 10 and c["max_step_count_difference"] <= 1
+        h, q = n // 2, n // 4
+        a, b, small = trace(0, h), trace(h, n), trace(0, q)       # 6.25 M each: pooled; 3.1 M: not
+        for k in ("index", "length", "n_steps", "position"):
+            assert torch.equal(torch.cat([a[k], b[k]]), t[k]), k
+            assert torch.equal(small[k], t[k][:q]), k
+    finally:
+        terrain.close()
+
+
 def test_c5_at_full_size():
     import torch
     terrain, bench = _terrain((40, 0, 10, 10), "tif")
