@@ -332,7 +332,11 @@ TURTLE_API int turtle_amd_compute_units(void);
  * loop.  The batch calls (`_n`) run on the GPU whatever this says; a geometry with a
  * projected map stays with the kernels; and a usable device is required either way:
  * this is an option of a GPU library, not a fallback for machines without one.
- * Process-wide; set it before the stepping starts. */
+ * Process-wide; set it before the stepping starts.  Without a call, the environment decides
+ * at the first scalar call: TURTLE_AMD_SCALAR=host (a caller relinked against this library,
+ * its source unchanged: examples/reference_loop.c); a call wins over the variable.  A stack
+ * that threads share has lock / unlock callbacks, as in the reference; a host lookup in it
+ * holds its tile against the other threads' loads while it reads it. */
 enum turtle_amd_scalar { TURTLE_AMD_SCALAR_DEVICE = 0, TURTLE_AMD_SCALAR_HOST = 1 };
 TURTLE_API void turtle_amd_scalar_set(int mode);
 TURTLE_API int turtle_amd_scalar_get(void);
