@@ -615,6 +615,44 @@ def run_workload(name, args, env, headline):
     return out
 
 
+def run_micro(env, n=20_000_000):
+    """The path's bandwidth-shaped batch kernels alone, once each (the
+    ECEF transforms, the bilinear lookup, stepper_position): points/s and algorithmic bytes (the arrays
+    a call reads and writes + 8 B of nodes where it looks a cell up) over the kernel's time."""
+    import torch
+    import turtle_amd as TA
+    dev = env["dev"]
+    terrain = Terrain(TA, (45, 3, 1, 1), False, env)
+    try:
+        g = torch.Generator(device=dev)
+        g.manual_seed(SEED)
+        lat = 45.05 + 0.9 * torch.rand(n, dtype=torch.float64, device=dev, generator=g)
+        lon = 3.05 + 0.9 * torch.rand(n, dtype=torch.float64, device=dev, generator=g)
+        h = 1000.0 * torch.rand(n, dtype=torch.float64, device=dev, generator=g)
+        ecef = TA.ecef_from_geodetic(lat, lon, h)
+        out = {}
+        for name, call, nbytes in (
+                ("ecef_from_geodetic_n", lambda: TA.ecef_from_geodetic(lat, lon, h), 24 + 24),
+                ("ecef_to_geodetic_n", lambda: TA.ecef_to_geodetic(ecef), 24 + 24),
+                ("map_elevation_n", lambda: terrain.handle.elevation(lon, lat), 16 + 8 + 4 + 8),
+                ("stepper_position_n", lambda: terrain.stepper.position(lat, lon, 500.0), 24 + 24 + 4 + 8)):
+            call()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                call()
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / 5
+            out[name] = {"points_per_s": n / (ms * 1e-3), "ms": ms, "bytes_per_point": nbytes,
+                         "gbs": n * nbytes / (ms * 1e-3) / 1e9,
+                         "frac_of_hbm": n * nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        return {"points": n, "kernels": out}
+    finally:
+        terrain.close()
+
+
 DEFAULT_ALSO = "c3,c3@8,c4,c5,c5!step_n,c2!strict,c3!strict"
 LINE_LIMIT = 6000           # bytes of the last stdout line (the driver keeps an 8 KB tail)
 
@@ -654,7 +692,7 @@ def short_leg(r):
     return out
 
 
-def final_line(head, extra, args, world, backend, comm_size):
+def final_line(head, extra, args, world, backend, comm_size, micro=None):
     """The LAST stdout line: the headline (everything from one timed region, one batch at a
     time) and one short object per further workload; the full records went out before it."""
     kernel = head["kernel"]
@@ -687,6 +725,9 @@ def final_line(head, extra, args, world, backend, comm_size):
                                 "kind": c["kind"], "sample": _short(c["sample"], 200)}
     if extra:
         line["also"] = {k: short_leg(r) for k, r in extra.items()}
+    if micro is not None:
+        line["micro"] = {k: {"points_per_s": v["points_per_s"], "frac_of_hbm": v["frac_of_hbm"]}
+                         for k, v in micro["kernels"].items()}
     line = _round(line)
     if len(json.dumps(line)) >= LINE_LIMIT:      # never lose the headline to a long line
         line["also"] = {k: {"value": v["value"], "ms_per_pass": v["ms_per_pass"]}
@@ -809,9 +850,13 @@ def main():
             print(json.dumps({"leg": key, **r}), flush=True)
             extra[key] = r
 
+    micro = None
+    if args.workload is None and world == 1 and args.also is None:
+        micro = run_micro(env)
+        print(json.dumps({"leg": "micro", **micro}), flush=True)
     if rank == 0:
         print(json.dumps(final_line(head, extra, args, world, env["backend"],
-                                    dist.get_world_size() if world > 1 else 1)), flush=True)
+                                    dist.get_world_size() if world > 1 else 1, micro)), flush=True)
 
     if world > 1:
         dist.destroy_process_group()

@@ -39,7 +39,11 @@ def test_last_line_is_short_and_carries_the_headline():
     import bench
     args = argparse.Namespace(steps=20, warmup=5)
     legs = {k: _record(k) for k in bench.DEFAULT_ALSO.replace("@8", "_stack_size_8").replace("!", "_").split(",")}
-    line = bench.final_line(_record("c2"), legs, args, 1, "nccl", 1)
+    micro = {"points": 20_000_000, "kernels": {f"kernel_{i}_of_the_path_n": {
+        "points_per_s": 1.0123456e11, "ms": 0.4941234, "bytes_per_point": 48, "gbs": 4861.1234, "frac_of_hbm": 0.60761234}
+        for i in range(4)}}
+    line = bench.final_line(_record("c2"), legs, args, 1, "nccl", 1, micro)
+    assert set(line["micro"]) == set(micro["kernels"])
     text = json.dumps(line)
     assert len(text) < bench.LINE_LIMIT, len(text)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
