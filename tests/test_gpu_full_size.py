@@ -97,7 +97,7 @@ def test_c3_at_full_size():
 
 def test_c4_at_full_size_with_the_ray_pool():
     """C4's share of one GPU (12.5 M rays over one 3601^2 tile): the size at which the lined pass's
-    waves exchange rays through LDS (device.hip, RayPool: on for one map from 4 M rays).  A 100 000-ray
+    waves exchange rays through LDS (device.hip, RayPool: on for one map from 6 M rays).  A 100 000-ray
     sample against the CPU restatement, the device's totals, and the whole batch bit for bit against
     two halves -- each of which is ALSO above the threshold -- and against a quarter, which is below
     it and runs the kernel without the pool: the pool changes no bit at this size either."""

@@ -210,18 +210,21 @@ def test_sorted_hand_over_changes_no_bit(tmp_path):
     ground at the back, which the lined pass reads last.  Where a ray is listed
     changes when it is traced, not what comes out: the same bits with the list unsorted
     (TURTLE_AMD_SORT_LONG=0), at the default, with every ray at the back and with a figure that
-    splits the batch in the middle."""
+    splits the batch in the middle.  Round 4: between the passes the front of the list is ORDERED,
+    the shallowest rays first (a radix sort on a one-byte key: TURTLE_AMD_SORT_KEY) -- on, off,
+    and on with the two-ended list off or all at the back: the same bits again."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     results = {}
-    for figure in ("0", "120", "1000000", "400"):
-        out = os.path.join(tmp_path, f"sort{figure}.npz")
-        env = dict(os.environ, TURTLE_AMD_SORT_LONG=figure)
+    for figure, key in (("0", "0"), ("120", "0"), ("1000000", "0"), ("400", "0"), ("120", "1"), ("0", "1"),
+                        ("1000000", "1"), ("400", "1")):
+        out = os.path.join(tmp_path, f"sort{figure}_{key}.npz")
+        env = dict(os.environ, TURTLE_AMD_SORT_LONG=figure, TURTLE_AMD_SORT_KEY=key)
         subprocess.run([sys.executable, os.path.join(here, "creep_probe.py"), out,
-                        os.path.join(tmp_path, f"work{figure}")], check=True, env=env, timeout=300)
-        results[figure] = dict(np.load(out))
-    base = results["0"]
+                        os.path.join(tmp_path, f"work{figure}_{key}")], check=True, env=env, timeout=300)
+        results[(figure, key)] = dict(np.load(out))
+    base = results[("0", "0")]
     assert base["map_n_steps"].max() > 2000 and base["stack_n_steps"].max() > 2000
     for figure, r in results.items():
         for key, ref in base.items():

@@ -32,6 +32,7 @@
  *   k_tally         hit counts + path-length histogram (uint64, exact)
  */
 #include <hip/hip_runtime.h>
+#include <hipcub/device/device_radix_sort.hpp>
 
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -2099,6 +2100,8 @@ struct PhaseIO {
         int mark_at;
         float long_if;          /* A: to the front, if expected to take more further steps than this */
         int pool;               /* B: the waves of a block exchange rays through LDS (RayPool) */
+        unsigned char * sort_key; /* A: the key the hand-over list is ordered by before B reads it, per
+                                 * place on the list (or NULL: B reads it as it was filled) */
 };
 
 /* CROSS: a ray whose step crossed a boundary is not bisected here (ST_BISECT
@@ -2840,10 +2843,27 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 const ull mine = back ? bmask : fmask;
                                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32),
                                     __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
-                                if (back)
-                                        ph.parked[capacity - 1 - (long)(base_back + rank)] = (int)ray;
-                                else
-                                        ph.parked[base + rank] = (int)ray;
+                                const long place = back ? capacity - 1 - (long)(base_back + rank) : (long)(base + rank);
+                                ph.parked[place] = (int)ray;
+                                if (!MODEL && (ph.sort_key != nullptr)) {
+                                        /* The lined pass ends waiting for its longest rays, and the
+                                         * later one of those is drawn, the longer: the front of the
+                                         * list is ordered by how shallow a ray goes -- the sine of its
+                                         * elevation angle, d . up (up ~ B / |B|: the geocentric
+                                         * vertical, 0.2 degrees off at most) -- the shallowest first:
+                                         * they are the ones that skim the ground for thousands of
+                                         * steps (measured by ordering a batch's INPUT that way: C2 3.37
+                                         * -> 3.01 ms).  The back of the list (rays that cannot be long)
+                                         * keeps its place behind everything: the largest key. */
+                                        const double up = __builtin_fma(dx, bx, __builtin_fma(dy, by, dz * bz)) *
+                                            __builtin_amdgcn_rsq(__builtin_fma(bx, bx, __builtin_fma(by, by, bz * bz)));
+                                        /* (one byte: 253 levels up to 14 degrees -- one pass of the sort;
+                                         * 254 is a place nobody filled, 255 the back) */
+                                        /* (tried instead: the steps the ray would take over flat ground at
+                                         * that angle from its clearance, on a log scale: no better) */
+                                        const double scaled = fmin(fabs(up) * 1024., 253.);
+                                        ph.sort_key[place] = back ? (unsigned char)255 : (unsigned char)scaled;
+                                }
                                 pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
                                 index[2 * ray] = m, index[2 * ray + 1] = k;
                                 length[ray] = len;
@@ -3904,14 +3924,30 @@ static int sort_long_if(void)
  * one map, 12.5 M rays (C4) 27.0 -> 26.0-26.4 ms; one map, 1 M rays (C2) 3.37 -> 3.55-3.72 ms
  * (a batch that small is as long as its longest rays' own chains, and a ray moves slower in a
  * wave that is kept full); a stack, 10 M rays (C3) 25.4 -> 31.7-33.9 ms (the stack's pooled
- * kernel spills 312 bytes a lane at three waves a SIMD).  So: one map, from 4 M rays on.
+ * kernel spills 312 bytes a lane at three waves a SIMD); one map at 3 / 4 / 6 M rays: 8.29 ->
+ * 8.42, 10.84 -> 11.15, 13.95 -> 13.74 ms.  So: one map, from 6 M rays on.
  * TURTLE_AMD_POOL=0 / 1: never / wherever the kernel exists. */
 static int pool_on(int mode, long n)
 {
         static int value = -2;
         if (value == -2) value = env_int("TURTLE_AMD_POOL", -1);
         if (value >= 0) return value;
-        return (mode == TAMD_MODE_ONE_MAP) && (n >= 4000000);
+        return (mode == TAMD_MODE_ONE_MAP) && (n >= 6000000);
+}
+/* Is the hand-over ordered between the passes (run_trace)?  A batch of a few million rays is as
+ * long as its longest rays' own chains, and drawing those first is worth more than the sort costs
+ * (TURTLE_AMD_SORT_KEY: 0 never, 1 always, else up to that many rays). */
+static int sort_hand_over(int mode, long n)
+{
+        static long value = -2;
+        (void)mode;
+        if (value == -2) {
+                const char * env = getenv("TURTLE_AMD_SORT_KEY");
+                value = ((env != nullptr) && (*env != 0)) ? atol(env) : -1;
+        }
+        if (value == 0) return 0;
+        if (value == 1) return 1;
+        return n <= ((value > 1) ? value : 4000000L);
 }
 static int drain_lanes(void)
 {
@@ -3942,6 +3978,8 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
     double * cross_ds, Paging pg, ull * stats, ull * queue)
 {
         const bool again = (pg.ids != nullptr);
+        const bool sort_room = (flags & TAMD_TRACE_SORT_ROOM) != 0;
+        flags &= ~TAMD_TRACE_SORT_ROOM;
         if (again) flags |= TRACE_CARRY_MEDIUM;
         const int resume = again ? 2 : 0;
         const bool strict = g_math_strict || !view.fast_ok;
@@ -3987,9 +4025,35 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
                 a.long_if = (float)long_if;
                 b.n_dev_back = queue + 4 * kQ;
         }
+        /* Room to ORDER the hand-over (internal.h, TAMD_TRACE_SORT_ROOM): keys beside the list, a
+         * radix sort (hipCUB) of the whole list's n places between the two passes -- places nobody
+         * filled carry a key (254) between the front's (0 .. 253) and the back's (255), so the front comes out first, in
+         * order, and the back stays at the far end, where the lined pass looks for it.  For batches
+         * small enough to be as long as their longest rays (sort_hand_over()). */
+        const bool order = sort_room && !again && (a.n_parked_back != nullptr) && sort_hand_over(MODE, n);
+        hipcub::DoubleBuffer<unsigned char> keys((unsigned char *)(parked + 5 * n), (unsigned char *)(parked + 6 * n));
+        hipcub::DoubleBuffer<int> ids(parked, parked + 4 * n);
+        void * const sort_temp = (void *)(parked + TAMD_TRACE_SORT_INTS * n);
+        size_t temp_bytes = 0;
+        bool sorting = false;
+        if (order) {
+                if ((hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, ids, (int)n, 0, 8, g_stream) ==
+                        hipSuccess) &&
+                    (temp_bytes <= TAMD_TRACE_SORT_TEMP)) {
+                        sorting = true;
+                        a.sort_key = keys.Current();
+                        HIP_TRY(hipMemsetAsync(keys.Current(), 0xFE, (size_t)n, g_stream));
+                }
+        }
         if (launch_trace<MODE, true, false>(view, n, again, pos, dir, max_steps, index, length,
                 n_steps, flags, a, stats, queue))
                 return 1;
+        if (sorting) {
+                if (hipcub::DeviceRadixSort::SortPairs(sort_temp, temp_bytes, keys, ids, (int)n, 0, 8, g_stream) !=
+                    hipSuccess)
+                        return fail("hipcub::DeviceRadixSort", hipGetLastError());
+                b.ids = ids.Current();
+        }
         if (launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
                 n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1 * kQ))
                 return 1;
@@ -4019,7 +4083,8 @@ extern "C" int tamd_k_trace(struct tamd_view view, long n, double * pos,
         if (pg.ids == nullptr) HIP_TRY(hipMemsetAsync(stats, 0, 4 * sizeof(ull), g_stream));
         HIP_TRY(hipMemsetAsync(queue, 0, 5 * kQ * sizeof(ull), g_stream));
         if (n <= 0) return 0;
-        const int carry = (flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0;
+        const int carry = ((flags & TURTLE_AMD_TRACE_RESUME) ? TRACE_CARRY_MEDIUM : 0) |
+            ((parked != nullptr) ? (flags & TAMD_TRACE_SORT_ROOM) : 0);
         if (view.mode == TAMD_MODE_ONE_MAP)
                 return run_trace<TAMD_MODE_ONE_MAP>(view, n, pos, dir, max_steps, index, length,
                     n_steps, carry, parked, cross_ds, pg, stats, queue);

@@ -211,8 +211,14 @@ int tamd_k_step(struct tamd_view view, long n, double * pos,
  * parked: int[3 n] and cross_ds: double[n], scratch for the lists of rays handed
  * from pass to pass (the long rays; the rays that crossed a boundary, for
  * k_cross), or NULL for a single-pass launch that bisects in place; with them,
- * length and n_steps must not be NULL. */
+ * length and n_steps must not be NULL.  With TAMD_TRACE_SORT_ROOM in `flags`,
+ * `parked` has room for TAMD_TRACE_SORT_INTS x n ints and TAMD_TRACE_SORT_TEMP
+ * bytes more behind them: the hand-over list is then ORDERED before the lined
+ * pass reads it (run_trace in device.hip). */
 #define TAMD_TRACE_COUNTERS 96
+#define TAMD_TRACE_SORT_ROOM 0x100
+#define TAMD_TRACE_SORT_INTS 7
+#define TAMD_TRACE_SORT_TEMP ((size_t)32 << 20)
 int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length,
     int * n_steps, int flags, int * parked, double * cross_ds, struct tamd_paging pg,

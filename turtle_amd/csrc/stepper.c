@@ -677,7 +677,8 @@ static int tamd_stepper_scratch(struct turtle_stepper * stepper, long n)
                 tamd_dev_free(stepper->d_parked);
                 stepper->d_parked = NULL;
         }
-        const size_t ints = (((size_t)n * 4 * sizeof(int) + 255) / 256) * 256;
+        /* (the lists of the passes, and room to order the hand-over: internal.h) */
+        const size_t ints = ((((size_t)n * TAMD_TRACE_SORT_INTS * sizeof(int) + TAMD_TRACE_SORT_TEMP) + 255) / 256) * 256;
         stepper->parked_capacity = 0;
         if (tamd_dev_malloc((void **)&stepper->d_parked, ints + (size_t)n * 4 * sizeof(double))) {
                 stepper->parked_capacity = -1;
@@ -894,7 +895,7 @@ static int trace_round(struct turtle_stepper * stepper, struct tamd_paging pg, i
         /* the lists of the passes; the packed media of the crossings hold 16 bits each */
         const int listed = a->scratch && (stepper->n_layers < 65000) && (stepper->n_data < 65000);
         return tamd_k_trace(stepper->view, a->n, a->pos, a->dir, a->max_steps, a->index, a->length,
-            a->n_steps, a->flags, listed ? stepper->d_parked : NULL,
+            a->n_steps, a->flags | (listed ? TAMD_TRACE_SORT_ROOM : 0), listed ? stepper->d_parked : NULL,
             listed ? stepper->d_scratch_ds + a->n : NULL, pg, stepper->d_stats, stepper->d_stats + 4);
 }
 
