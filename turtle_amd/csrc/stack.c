@@ -189,7 +189,7 @@ static int stage_acquire(struct turtle_stack * s, size_t bytes, int tile, int * 
                 s->stage_device[k] = -2;
                 s->stage_stamp[k] = ++s->clock;
                 *cached = 1;
-                tamd_stack_buffer_hits++;
+                __atomic_add_fetch(&tamd_stack_buffer_hits, 1, __ATOMIC_RELAXED);
                 return k;
         }
         for (k = 0; k < TAMD_STAGE_SLOTS; k++) {
