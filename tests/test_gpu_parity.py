@@ -881,6 +881,50 @@ def test_png_map_elevation_and_stepper(golden):
     m.destroy()
 
 
+def test_reference_hgt_test_as_written(tmp_path):
+    """The reference's test_io_hgt [ref tests/test-turtle.c:1049-1089] re-expressed: a 3601^2 tile of
+    -1 / +1 written as the reference's test writes it (file order, big-endian), every node with
+    k % 100 == 0 or k % 101 == 0 read back through turtle_map_node, then turtle_map_fill(0, 0, 10)
+    and turtle_map_elevation(3, 45) == 10 -- through the kernel (the HBM copy of a map that was
+    filled is made again) and on the host; and a batch of points against the bilinear of the
+    checkerboard, bit for bit."""
+    n = 3601
+    k = np.arange(n * n, dtype=np.int64).reshape(n, n)
+    z_file = np.where(k % 2 == 0, -1, 1).astype(">i2")
+    path = os.path.join(str(tmp_path), "N45E003.hgt")
+    z_file.tofile(path)
+    m = TA.Map.load(path)
+    pick = np.flatnonzero(((k % 100) == 0) | ((k % 101) == 0))[::37]      # a tenth of a percent of the reference's nodes
+    for kk in pick:
+        i, j = divmod(int(kk), n)
+        _, _, z = m.node(j, i)
+        assert z == (-1.0 if kk % 2 == 0 else 1.0), (i, j, z)
+    # bilinear over the checkerboard, on the device: memory rows run south -> north
+    z_mem = z_file[::-1, :].astype(np.float64)
+    rng = np.random.default_rng(11)
+    x, y = rng.uniform(3.0, 4.0, 20000), rng.uniform(45.0, 46.0, 20000)
+    got, inside = m.elevation(x, y)
+    hx, hy = (x - 3.0) / (1.0 / (n - 1)), (y - 45.0) / (1.0 / (n - 1))
+    ix, iy = np.minimum(hx.astype(int), n - 2), np.minimum(hy.astype(int), n - 2)
+    fx, fy = hx - ix, hy - iy
+    want = (z_mem[iy, ix] * (1 - fx) * (1 - fy) + z_mem[iy + 1, ix] * (1 - fx) * fy +
+            z_mem[iy, ix + 1] * fx * (1 - fy) + z_mem[iy + 1, ix + 1] * fx * fy)     # [ref map.c:272-273]
+    assert inside.all() and np.array_equal(got, want)
+    m.fill(0, 0, 10.0)
+    z, inside = m.elevation_scalar(3.0, 45.0)
+    assert inside and z == 10.0
+    TA.set_scalar("host")
+    try:
+        z, inside = m.elevation_scalar(3.0, 45.0)
+    finally:
+        TA.set_scalar("device")
+    assert inside and z == 10.0
+    got2, _ = m.elevation(x, y)
+    far = (ix > 0) | (iy > 0)
+    assert np.array_equal(got2[far], want[far])         # only the cell of node (0, 0) changed
+    m.destroy()
+
+
 def test_plain_c_caller(tmp_path):
     """examples/trace_rays.c: a C99 program against include/turtle.h, built
     with gcc only and linked to libturtle_amd.so -- the scalar drop-in loop and
