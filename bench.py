@@ -51,6 +51,7 @@ VALU_CLOCK_HZ = 2.4e9       # MI355X peak engine clock (MI355X_MICROARCH.md)
 TRACE_KERNEL = "k_trace (phase A: every ray by the closed form up to its hand-over step, 32 or 512; phase B: the rest on their lines) + k_cross (every crossing, packed)"
 STEP_KERNELS = "k_step_fast + k_bisect per generation (single steps, directions drawn in the kernel)"
 STEP_N_KERNELS = "k_step_fast + k_bisect per generation (turtle_stepper_step_n, TURTLE_AMD_STEP_RESUME, the caller's directions)"
+WALK_N_KERNELS = "k_step_fast + k_bisect per generation (turtle_stepper_walk_n: one double of state a ray, the caller's directions)"
 WALK_KERNEL = "k_walk (a ray's whole walk in one launch: state in registers, directions drawn in the kernel)"
 SEED = 0x5EED2026
 PARITY_RAYS = 100_000
@@ -324,6 +325,7 @@ def run_workload(name, args, env, headline):
     del t_lat, t_lon, t_az, t_el
     scatter = name == "c5"
     gens = getattr(args, "step_n", 0) if scatter else 0     # > 0: the walk through turtle_stepper_step_n
+    compact = bool(getattr(args, "compact", False))         # ... through turtle_stepper_walk_n instead
     if gens:
         args.scatter_steps = gens
     # ---- batches in flight: a stepper, a stream and a set of arrays each (one stepper is
@@ -367,7 +369,7 @@ def run_workload(name, args, env, headline):
         turtle_stepper_step_n, each resumed from the sample the one before returned
         (TURTLE_AMD_STEP_RESUME), latitude and longitude not asked for.  `count`: an UNTIMED
         replica that also sums what the caller of a real walk would (lengths, steps)."""
-        st = f.stepper.step(f.pos, None, outputs=False)
+        st = f.stepper.walk(f.pos) if compact else f.stepper.step(f.pos, None, outputs=False)
         if count:
             total = torch.zeros(n, dtype=torch.float64, device=dev)
             taken = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -377,7 +379,8 @@ def run_workload(name, args, env, headline):
         for k in range(gens):
             if count:
                 alive = st["index"][:, 0] >= 0
-            st = f.stepper.step(st["position"], dirs[k], resume=st)
+            st = f.stepper.walk(None, dirs[k], state=st) if compact else \
+                f.stepper.step(st["position"], dirs[k], resume=st)
             if count:
                 total += torch.where(alive, st["step"], torch.zeros_like(total))
                 taken += alive.to(torch.int32)
@@ -497,7 +500,8 @@ def run_workload(name, args, env, headline):
             samples_per_step = stats["samples"] / max(1, stats["steps"])
             alg_bytes = (8.0 * samples_per_step + 88.0) * stats["steps"]
             per_launch = alg_bytes / launches
-            kernel = {"name": (STEP_N_KERNELS if gens else STEP_KERNELS) if by_steps else WALK_KERNEL,
+            kernel = {"name": ((WALK_N_KERNELS if compact else STEP_N_KERNELS) if gens else STEP_KERNELS)
+                      if by_steps else WALK_KERNEL,
                       "ms": kernel_ms, "launches_per_step": launches,
                       "ms_per_generation": gen_ms if gens else kernel_ms / args.scatter_steps,
                       "steps_per_pass": stats["steps"], "samples_per_pass": stats["samples"],
@@ -516,7 +520,8 @@ def run_workload(name, args, env, headline):
                       "rays_stopped_at_max_steps": stats["capped"]}
             bytes_note = "SURVEY 8d trace mode: 8 B x samples + 64 B x rays"
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src, valu = measured_traffic(name + ("_step_n" if gens else ""), n, TA.get_math())
+        traffic, traffic_src, valu = measured_traffic(
+            name + (("_walk_n" if compact else "_step_n") if gens else ""), n, TA.get_math())
         if use_stack and args.stack_size:
             # the counters were taken with every tile resident: they say nothing of a paged pass
             traffic, traffic_src, valu = None, None, None
@@ -525,7 +530,8 @@ def run_workload(name, args, env, headline):
         out = {
             "value": value, "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
             "config": {"workload": text.replace("{steps}", str(args.scatter_steps)) +
-                       (" -- through turtle_stepper_step_n, the caller's directions" if gens else "") + (f" -- stack_size {args.stack_size}: tiles paged host->HBM "
+                       ((" -- through turtle_stepper_walk_n, the caller's directions" if compact else
+                         " -- through turtle_stepper_step_n, the caller's directions") if gens else "") + (f" -- stack_size {args.stack_size}: tiles paged host->HBM "
                                            f"by demand, {stepper.rounds} rounds in the last pass"
                                            if (use_stack and args.stack_size) else ""),
                        "rays_per_gpu": n, "max_steps": args.max_steps,
@@ -653,7 +659,7 @@ def run_micro(env, n=20_000_000):
         terrain.close()
 
 
-DEFAULT_ALSO = "c3,c3@8,c4,c5,c5!step_n,c2!strict,c3!strict"
+DEFAULT_ALSO = "c3,c3@8,c4,c5,c5!step_n,c5!walk_n,c2!strict,c3!strict"
 LINE_LIMIT = 6000           # bytes of the last stdout line (the driver keeps an 8 KB tail)
 
 
@@ -768,6 +774,8 @@ def main():
     ap.add_argument("--step-n", type=int, default=0,
                     help="c5 only: the walk through turtle_stepper_step_n with TURTLE_AMD_STEP_RESUME and "
                          "the CALLER's directions (drawn beforehand), this many generations a pass")
+    ap.add_argument("--compact", action="store_true",
+                    help="with --step-n: through turtle_stepper_walk_n (one double of state a ray between the calls)")
     ap.add_argument("--generations", type=int, default=64, help="generations of the default c5!step_n leg")
     ap.add_argument("--tiles", choices=("auto", "hgt", "tif"), default="auto",
                     help="tile files: SRTM's .hgt, ASTER-GDEM2's GeoTIFF-16 (auto: tif for c5, hgt else)")
@@ -830,11 +838,13 @@ def main():
     for leg in [w for w in also.split(",") if w and w != "none"]:
         name = leg
         sub = argparse.Namespace(**vars(args))
-        sub.rays, sub.blocks, sub.sort, sub.sort_steps, sub.stack_size, sub.step_n = 0, 1, 0, 0, 0, 0
+        sub.rays, sub.blocks, sub.sort, sub.sort_steps, sub.stack_size, sub.step_n, sub.compact = 0, 1, 0, 0, 0, 0, False
         if name.endswith("@8"):      # C3's second leg: the same workload, 8 of its 16 tiles resident
             name, sub.stack_size = name[:-2], 8
         if name.endswith("!step_n"):  # C5 through turtle_stepper_step_n, the caller's directions
             name, sub.step_n = name[:-7], args.generations
+        if name.endswith("!walk_n"):  # ... through turtle_stepper_walk_n: one double of state a ray
+            name, sub.step_n, sub.compact = name[:-7], args.generations, True
         strict = name.endswith("!strict")   # the reference's arithmetic, operand for operand
         if strict:
             name, sub.no_cpu = name[:-7], True
@@ -846,7 +856,7 @@ def main():
                 TA.set_math(os.environ.get("TURTLE_AMD_MATH", "fast"))
         if rank == 0:
             key = (name + (f"_stack_size_{sub.stack_size}" if sub.stack_size else "")
-                   + ("_step_n" if sub.step_n else "") + ("_strict" if strict else ""))
+                   + (("_walk_n" if sub.compact else "_step_n") if sub.step_n else "") + ("_strict" if strict else ""))
             print(json.dumps({"leg": key, **r}), flush=True)
             extra[key] = r
 

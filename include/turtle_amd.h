@@ -414,6 +414,22 @@ TURTLE_API enum turtle_return turtle_stepper_step_n(
     double * longitude, double * altitude, double * elevation /* [n][2] */,
     double * step, int * index /* [n][2] */, int flags, int space);
 
+/* The same steps for a walk that keeps the LEAST state between its calls.  What a step resumes
+ * from is the medium the ray is in and the tentative length its last sample gave it [impl
+ * stepper.c:799-813: all the reference reads its cached sample for]: `next` holds that length --
+ * one double in, one out, where turtle_stepper_step_n with TURTLE_AMD_STEP_RESUME moves altitude and
+ * two elevations each way (a third of what a step streams; a batch of single steps is bound by its
+ * memory traffic) -- and `index` the medium.  direction == NULL begins a walk: the positions are
+ * sampled, `next` and `index` filled (step[], if given, is that tentative length too); with a
+ * direction every ray with index[r][0] >= 0 takes the step turtle_stepper_step would: position
+ * advanced in place, step[r] its length, index[r] and next[r] for the one after.  A ray that has
+ * left the data (index[r][0] = -1) takes no step.  The same arithmetic on the same values as the
+ * RESUME form: the same bits. */
+TURTLE_API enum turtle_return turtle_stepper_walk_n(
+    struct turtle_stepper * stepper, long n, double * position /* [n][3] */,
+    const double * direction /* [n][3], or NULL to begin */, double * next /* [n], in / out */,
+    double * step /* [n] or NULL */, int * index /* [n][2], in / out */, int space);
+
 /* Flags of turtle_stepper_scatter_n. */
 enum turtle_amd_scatter_flags {
         /* Begin a walk: sample the positions first (as turtle_stepper_step_n with

@@ -149,14 +149,15 @@ static int stack_unlock(void) { return pthread_mutex_unlock(&stack_mutex); }
  * `threads` workers with a client each; walk_steps > 0: the scattering walk of C5,
  * direction[walk_steps][n][3], else the trace to the first boundary, direction[n][3].
  * The tiles are loaded before the clock starts (stack_size 0: all of them). */
-long ref_stack_n(const char * stack_path, int stack_size, double range, double slope,
+static long stack_n(int locked, const char * stack_path, int stack_size, double range, double slope,
     double resolution, long n, double * position, const double * direction, int max_steps,
     int walk_steps, int * index, double * length, int * n_steps, int threads, double * seconds)
 {
         turtle_error_handler_set(NULL);
         struct turtle_stack * stack = NULL;
-        if (turtle_stack_create(&stack, stack_path, stack_size, &stack_lock, &stack_unlock) !=
-            TURTLE_RETURN_SUCCESS)
+        if (!locked) threads = 1; /* a stack without lock / unlock is one thread's [ref include/turtle.h:620-626] */
+        if (turtle_stack_create(&stack, stack_path, stack_size, locked ? &stack_lock : NULL,
+                locked ? &stack_unlock : NULL) != TURTLE_RETURN_SUCCESS)
                 return -1;
         if (turtle_stack_load(stack) != TURTLE_RETURN_SUCCESS) {
                 turtle_stack_destroy(&stack);
@@ -194,4 +195,26 @@ long ref_stack_n(const char * stack_path, int stack_size, double range, double s
         free(tid);
         turtle_stack_destroy(&stack);
         return steps;
+}
+
+long ref_stack_n(const char * stack_path, int stack_size, double range, double slope,
+    double resolution, long n, double * position, const double * direction, int max_steps,
+    int walk_steps, int * index, double * length, int * n_steps, int threads, double * seconds)
+{
+        return stack_n(1, stack_path, stack_size, range, slope, resolution, n, position, direction, max_steps,
+            walk_steps, index, length, n_steps, threads, seconds);
+}
+
+/* The same through a stack WITHOUT lock / unlock, one thread: the stepper then looks the stack up
+ * directly (turtle_stack_elevation), not through a client of its own -- whose memo of "no data at
+ * this integer (latitude, longitude)" [ref client.c:117-124, :157-160] truncates toward zero, so that
+ * a point at longitude -0.3 and a point at +0.3 share a memo cell: a ray that leaves a mosaic
+ * through its rim at longitude (or latitude) 0 is then located a degree too early (found in round 4
+ * on C5: docs/lab_notebook_r4.md). */
+long ref_stack_unlocked_n(const char * stack_path, int stack_size, double range, double slope,
+    double resolution, long n, double * position, const double * direction, int max_steps,
+    int walk_steps, int * index, double * length, int * n_steps, double * seconds)
+{
+        return stack_n(0, stack_path, stack_size, range, slope, resolution, n, position, direction, max_steps,
+            walk_steps, index, length, n_steps, 1, seconds);
 }

@@ -360,7 +360,7 @@ def trace_map(map_path, position, direction, local_range=1.0, slope=0.4, resolut
 
 
 def stack_run(stack_path, position, direction, walk_steps=0, stack_size=0, local_range=1.0, slope=0.4,
-              resolution=1e-2, max_steps=100000, threads=1):
+              resolution=1e-2, max_steps=100000, threads=1, locked=True):
     """n rays through the turtle_stack over the .hgt tiles in `stack_path`, stepped by the REAL
     reference: ONE stack with lock / unlock shared by `threads` pthreads, a client per worker (the
     reference's threaded example).  walk_steps = 0: each ray to its first boundary, direction[n][3];
@@ -376,10 +376,17 @@ def stack_run(stack_path, position, direction, walk_steps=0, stack_size=0, local
     nsteps = np.empty(n, dtype=np.int32)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
     seconds = C.c_double(0.0)   # the stepping alone: the tiles are loaded before the clock starts
-    total = L.ref_stack_n(os.fsencode(stack_path), C.c_int(stack_size), D(local_range), D(slope),
-                          D(resolution), C.c_long(n), vp(pos), vp(dire), C.c_int(max_steps),
-                          C.c_int(walk_steps), vp(index), vp(length), vp(nsteps), C.c_int(threads),
-                          C.byref(seconds))
+    if locked:
+        total = L.ref_stack_n(os.fsencode(stack_path), C.c_int(stack_size), D(local_range), D(slope),
+                              D(resolution), C.c_long(n), vp(pos), vp(dire), C.c_int(max_steps),
+                              C.c_int(walk_steps), vp(index), vp(length), vp(nsteps), C.c_int(threads),
+                              C.byref(seconds))
+    else:
+        # one thread, no lock / unlock: the stepper looks the stack up itself, no client (ref_driver.c)
+        L.ref_stack_unlocked_n.restype = C.c_long
+        total = L.ref_stack_unlocked_n(os.fsencode(stack_path), C.c_int(stack_size), D(local_range), D(slope),
+                                       D(resolution), C.c_long(n), vp(pos), vp(dire), C.c_int(max_steps),
+                                       C.c_int(walk_steps), vp(index), vp(length), vp(nsteps), C.byref(seconds))
     if total < 0:
         raise RuntimeError(f"the reference could not make a stack of {stack_path}")
     return dict(position=pos, index=index, length=length, n_steps=nsteps, total_steps=int(total),

@@ -61,6 +61,10 @@ for name in which:
         torch.cuda.synchronize()
         path = terrain.hgt_files()
         chunk, bad_medium, beyond, bad_steps, worst, secs, total = 500_000, 0, 0, 0, 0.0, 0.0, 0
+        # the reference's CLIENT (a locked stack) mislocates rays that leave through the rim at
+        # longitude 0 [ref client.c:117-124: its memo truncates toward zero]: the rays that differ
+        # from it go through the reference WITHOUT a client (an unlocked stack, one thread) as well
+        again, again_medium, again_beyond, again_steps, again_worst = 0, 0, 0, 0, 0.0
         t1 = time.time()
         for lo in range(0, n, chunk):
             hi = min(n, lo + chunk)
@@ -75,11 +79,29 @@ for name in which:
             beyond += int((~flipped & (rel > 1e-6)).sum())
             bad_steps += int((gs != a["n_steps"]).sum())
             worst = max(worst, float(rel[~flipped].max(initial=0.0)))
+            sel = np.flatnonzero(flipped | (rel > 1e-6) | (gs != a["n_steps"]))
+            if sel.size:
+                b = R.stack_run(path, pos0[lo:hi].cpu().numpy()[sel], np.ascontiguousarray(dirs[:, sel]),
+                                walk_steps=K, local_range=0.0, locked=False)
+                f2 = gi[sel, 0] != b["index"][:, 0]
+                r2 = np.abs(gl[sel] - b["length"]) / np.maximum(np.abs(b["length"]), 1e-300)
+                again += sel.size
+                again_medium += int(f2.sum())
+                again_beyond += int((~f2 & (r2 > 1e-6)).sum())
+                again_steps += int((gs[sel] != b["n_steps"]).sum())
+                again_worst = max(again_worst, float(r2[~f2].max(initial=0.0)))
             print(f"  c5 rays {lo}..{hi}: so far {bad_medium} with another medium, {beyond} beyond 1e-6, "
-                  f"{bad_steps} with another step count ({time.time() - t1:.0f} s)", flush=True)
+                  f"{bad_steps} with another step count than the reference's clients give; of those {again} rays "
+                  f"through the reference without a client: {again_medium} / {again_beyond} / {again_steps} "
+                  f"({time.time() - t1:.0f} s)", flush=True)
         print(f"c5: ALL {n} rays x {K} steps against the reference itself ({cores} threads, exact transform, "
               f"{secs:.0f} s of stepping, {total} steps): medium_mismatch {bad_medium}, beyond_1e-6 {beyond}, "
-              f"step_count_mismatch {bad_steps}, max_rel_path_length {worst:.3g}; steps GPU {int(w['steps'].sum())}",
+              f"step_count_mismatch {bad_steps}, max_rel_path_length {worst:.3g}; steps GPU {int(w['steps'].sum())}.\n"
+              f"    Those {again} rays (all of them rays that left the mosaic) against the reference WITHOUT a client "
+              f"(an unlocked stack, one thread): medium_mismatch {again_medium}, beyond_1e-6 {again_beyond}, "
+              f"step_count_mismatch {again_steps}, max_rel_path_length {again_worst:.3g} -- the reference's client "
+              f"memoises 'no data' per integer (latitude, longitude) by truncation toward zero [ref client.c:117-124], "
+              f"so a ray leaving through the rim at longitude 0 is located up to a degree early (lab notebook r4).",
               flush=True)
     terrain.close()
     print(f"  ({name}: {time.time() - t0:.0f} s in all)", flush=True)

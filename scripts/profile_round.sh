@@ -17,6 +17,10 @@ if [ "$wl" = c5_step_n ]; then
   # the walk through turtle_stepper_step_n, the caller's directions: two kernels a generation
   WL="--workload c5 --step-n 64 --rays $rays --also none --in-flight 1"; kernel="k_step|k_bisect"
 fi
+if [ "$wl" = c5_walk_n ]; then
+  # ... through turtle_stepper_walk_n: one double of state a ray between the calls
+  WL="--workload c5 --step-n 64 --compact --rays $rays --also none --in-flight 1"; kernel="k_step|k_bisect"
+fi
 out=gpurun_out/$tag
 mkdir -p $out
 timeout -k 10 600 python3 bench.py $WL > $out/bench.json 2> $out/bench.err

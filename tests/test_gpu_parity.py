@@ -777,6 +777,48 @@ def test_scatter_n_is_the_step_loop(math, tmp_path):
     stack.destroy()
 
 
+def test_walk_n_is_the_step_loop_with_less_state(math, tmp_path):
+    """turtle_stepper_walk_n (round 4): a walk's steps with ONE double of state a ray between the
+    calls -- the tentative length of its next step -- where turtle_stepper_step_n with
+    TURTLE_AMD_STEP_RESUME hands altitude and two elevations back and forth.  The same function of
+    the same sample, evaluated when the sample is taken instead of when the next step begins:
+    positions, step lengths and media equal bit for bit, step after step, in both arithmetics;
+    over one map and through a stack with a hole whose rim rays leave by; numpy and device arrays."""
+    import torch
+    m = B.c1_map()
+    stack = B.mosaic(tmp_path, [(45, 3), (45, 4), (46, 3)], 1201)
+    for terrain, box, add, height in ((m, (T.C1_Y, T.C1_X), "add_map", 20.0),
+                                      (stack, ((45.0, 47.0), (3.0, 5.0)), "add_stack", 3000.0)):
+        st = TA.Stepper()
+        getattr(st, add)(terrain, 0.0)
+        n, K = 4000, 20
+        lat, lon, _, _ = TA.synth.uniform_rays(n, box[0], box[1], seed=12)
+        pos, di = st.position(lat, lon, height)
+        pos = pos[di == 0]
+        n = pos.shape[0]
+        a = st.step(pos.copy(), None)
+        b = st.walk(pos.copy())
+        bd = st.walk(torch.as_tensor(pos, device="cuda").clone())
+        assert np.array_equal(a["index"], b["index"]) and np.array_equal(a["step"], b["next"])
+        left = 0
+        for k in range(K):
+            d = TA.isotropic(n, 31, k, first_ray=3, device=False)
+            a = st.step(a["position"], d, resume=a)
+            b = st.walk(None, d, state=b)
+            bd = st.walk(None, torch.as_tensor(d, device="cuda"), state=bd)
+            TA.synchronize()
+            for got in (b, {k_: v.cpu().numpy() for k_, v in bd.items()}):
+                assert np.array_equal(got["position"], a["position"]), k
+                assert np.array_equal(got["index"], a["index"]), k
+                assert np.array_equal(got["step"], a["step"]), k
+            left = int((a["index"][:, 0] < 0).sum())
+        if add == "add_stack":
+            assert left > 20           # rays did leave, and then took no further step
+        st.destroy()
+    m.destroy()
+    stack.destroy()
+
+
 def test_gradient_bit_exact(golden, tmp_path):
     """turtle_map_gradient / turtle_stack_gradient [ref map.c:280-392,
     stack.c:364-388]: +,-,*,/ only, so bit-exact, slip at map.c:353 included."""

@@ -535,6 +535,23 @@ class Stepper:
         out["position"] = pos
         return out
 
+    def walk(self, position, direction=None, state=None):
+        """turtle_stepper_walk_n: a walk's steps with the least state between the calls.
+        direction None begins it (returns the state: position, next, index, step); else `state`
+        = the dict the last call returned for these positions, updated in place."""
+        if state is None:
+            sp = _space_of(position)
+            pos = _as(position, sp).reshape(-1, 3)
+            n = pos.shape[0]
+            state = dict(position=pos, next=_new((n,), sp, like=pos), step=_new((n,), sp, like=pos),
+                         index=_new((n, 2), sp, np.int32, like=pos))
+        sp = _space_of(state["position"], direction)
+        n = state["position"].shape[0]
+        d = None if direction is None else _as(direction, sp).reshape(-1, 3)
+        _check(lib().turtle_stepper_walk_n(self.h, C.c_long(n), _ptr(state["position"]), _ptr(d),
+                                           _ptr(state["next"]), _ptr(state["step"]), _ptr(state["index"]), sp))
+        return state
+
     def scatter(self, position, seed, n_steps, first_ray=0, first_step=0, state=None):
         """turtle_stepper_scatter_n: `n_steps` generations of single steps in
         Philox(first_ray + r, generation; seed) directions, sums kept on the device.

@@ -1702,6 +1702,14 @@ __device__ __forceinline__ void step_items(const tamd_view & v, long n,
                 double listed_ds = 0.;
                 TileFault fault = { -1, 0, 0 }; /* tiles to page in: the ray is left as it is, and listed */
                 int home = -1;
+                /* TAMD_STEP_COMPACT (turtle_stepper_walk_n): all a step resumes from, besides the
+                 * medium, is the tentative length the last sample gave it [ref stepper.c:799-813:
+                 * what the cached sample is read for] -- `alt` holds THAT, one double in and one
+                 * out, and the altitude and the two elevations (24 B in, 24 B out) stay in
+                 * registers.  The same function of the same values, evaluated when the sample is
+                 * taken instead of when the next step begins: the same bits. */
+                const bool compact = (flags & TAMD_STEP_COMPACT) != 0;
+                double ds_given = -1.;
                 /* a walk: a ray that has left the data takes no further step */
                 if (walk.on && (r >= 0) && (index[2 * r] < 0)) r = -1;
                 if (r >= 0) {
@@ -1713,8 +1721,13 @@ __device__ __forceinline__ void step_items(const tamd_view & v, long n,
                          * longitude are not read: whatever becomes of the step,
                          * the ones published are the new sample's */
                         s.lat = 0., s.lon = 0.;
-                        s.alt = alt[r];
-                        s.e0 = elev[2 * r], s.e1 = elev[2 * r + 1];
+                        if (compact) {
+                                ds_given = alt[r];
+                                s.alt = 0., s.e0 = -DBL_MAX, s.e1 = DBL_MAX;
+                        } else {
+                                s.alt = alt[r];
+                                s.e0 = elev[2 * r], s.e1 = elev[2 * r + 1];
+                        }
                         s.m = index[2 * r], s.k = index[2 * r + 1];
                 } else {
                         d_sample<MODE, FAST>(v, ctx, px, py, pz, s);
@@ -1725,7 +1738,7 @@ __device__ __forceinline__ void step_items(const tamd_view & v, long n,
 
                 double ds = 0.;
                 if ((s.m >= 0) && (fault.centre < 0)) {
-                        ds = d_step_length(v, s.alt, s.e0, s.e1, s.m);
+                        ds = (ds_given >= 0.) ? ds_given : d_step_length(v, s.alt, s.e0, s.e1, s.m);
                         if (directed) {
                                 double dx, dy, dz;
                                 if (walk.on)
@@ -1783,8 +1796,8 @@ __device__ __forceinline__ void step_items(const tamd_view & v, long n,
                 if (!listed && (fault.centre < 0)) {
                         if (lat) lat[r] = s.lat;
                         if (lon) lon[r] = s.lon;
-                        if (alt) alt[r] = s.alt;
-                        if (elev) {
+                        if (alt) alt[r] = !compact ? s.alt : ((s.m >= 0) ? d_step_length(v, s.alt, s.e0, s.e1, s.m) : 0.);
+                        if (elev && !compact) {
                                 elev[2 * r] = (s.m >= 0) ? s.e0 : 0.;
                                 elev[2 * r + 1] = (s.m >= 0) ? s.e1 : 0.;
                         }
@@ -1848,10 +1861,11 @@ template <int MODE, bool FAST>
 __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict__ pos,
     const double * __restrict__ dir, double * __restrict__ lat, double * __restrict__ lon,
     double * __restrict__ alt, double * __restrict__ elev, double * __restrict__ step,
-    int * __restrict__ index, CrossList cross, Paging pg, ull * __restrict__ stats, StepWalk walk)
+    int * __restrict__ index, int flags, CrossList cross, Paging pg, ull * __restrict__ stats, StepWalk walk)
 {
         OneCtx ctx;
         d_load_ctx<MODE, FAST>(v, ctx);
+        const bool compact = (flags & TAMD_STEP_COMPACT) != 0; /* see step_items */
         const long n = (long)*cross.count;
         ull my_rays = 0, my_samples = 0;
         for (long i0 = blockIdx.x * (long)blockDim.x; i0 < n; i0 += (long)gridDim.x * blockDim.x) {
@@ -1915,8 +1929,8 @@ __global__ void __launch_bounds__(256) k_bisect(tamd_view v, double * __restrict
                 pos[3 * r] = px + dx * ds1, pos[3 * r + 1] = py + dy * ds1, pos[3 * r + 2] = pz + dz * ds1;
                 if (lat) lat[r] = s.lat;
                 if (lon) lon[r] = s.lon;
-                if (alt) alt[r] = s.alt;
-                if (elev) {
+                if (alt) alt[r] = !compact ? s.alt : ((s.m >= 0) ? d_step_length(v, s.alt, s.e0, s.e1, s.m) : 0.);
+                if (elev && !compact) {
                         elev[2 * r] = (s.m >= 0) ? s.e0 : 0.;
                         elev[2 * r + 1] = (s.m >= 0) ? s.e1 : 0.;
                 }
@@ -3723,10 +3737,10 @@ static int run_step(struct tamd_view view, long n, double * pos, const double * 
                 const dim3 few(grid_for(n / 10 + 1, 256));                                     \
                 if (strict)                                                                    \
                         hipLaunchKernelGGL((k_bisect<MODE, false>), few, block, 0, g_stream, view,     \
-                            pos, dir, lat, lon, alt, elev, step, index, cross, pg, stats, walk); \
+                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats, walk); \
                 else                                                                           \
                         hipLaunchKernelGGL((k_bisect<MODE, true>), few, block, 0, g_stream, view,      \
-                            pos, dir, lat, lon, alt, elev, step, index, cross, pg, stats, walk); \
+                            pos, dir, lat, lon, alt, elev, step, index, flags, cross, pg, stats, walk); \
                 LAUNCH_CHECK("k_bisect");                                                      \
         } while (0)
         if (view.mode == TAMD_MODE_ONE_MAP)

@@ -112,6 +112,7 @@ const char * turtle_error_function(turtle_function_t * caller)
         NAME(turtle_stack_elevation_n);
         NAME(turtle_stepper_position_n);
         NAME(turtle_stepper_step_n);
+        NAME(turtle_stepper_walk_n);
         NAME(turtle_stepper_trace_n);
         NAME(turtle_stepper_scatter_n);
         NAME(turtle_stepper_trace_stats);

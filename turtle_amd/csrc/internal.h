@@ -217,6 +217,9 @@ int tamd_k_step(struct tamd_view view, long n, double * pos,
  * pass reads it (run_trace in device.hip). */
 #define TAMD_TRACE_COUNTERS 96
 #define TAMD_TRACE_SORT_ROOM 0x100
+/* a flag of the step kernels beside enum turtle_amd_step_flags: `alt` holds the tentative length
+ * of the next step instead of the altitude, `elev` is not used (turtle_stepper_walk_n) */
+#define TAMD_STEP_COMPACT 0x200
 #define TAMD_TRACE_SORT_INTS 7
 #define TAMD_TRACE_SORT_TEMP ((size_t)32 << 20)
 int tamd_k_trace(struct tamd_view view, long n, double * pos,

@@ -715,7 +715,8 @@ static enum turtle_return step_n(struct tamd_error * error, struct turtle_steppe
         struct tamd_error error_ = *error;
         if ((position == NULL) || (index == NULL))
                 return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
-        if ((flags & TURTLE_AMD_STEP_RESUME) && ((altitude == NULL) || (elevation == NULL)))
+        if ((flags & TURTLE_AMD_STEP_RESUME) && !(flags & TAMD_STEP_COMPACT) &&
+            ((altitude == NULL) || (elevation == NULL)))
                 return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS,
                     "TURTLE_AMD_STEP_RESUME needs altitude, elevation and index");
         struct tamd_stage st;
@@ -869,6 +870,17 @@ enum turtle_return turtle_stepper_scatter_n(struct turtle_stepper * stepper, lon
             tamd_stage_fetch(&st, steps, n * sizeof(int), a.steps) || tamd_stage_end(&st))
                 return TAMD_RAISE_DEVICE();
         return TURTLE_RETURN_SUCCESS;
+}
+
+/* A walk, step by step, with the least state between the calls: `next` (the tentative length of
+ * the next step) and `index` are all a step resumes from [ref stepper.c:708-710, :799-813]. */
+enum turtle_return turtle_stepper_walk_n(struct turtle_stepper * stepper, long n, double * position,
+    const double * direction, double * next, double * step, int * index, int space)
+{
+        TAMD_ERROR_INIT(&turtle_stepper_walk_n);
+        if (next == NULL) return TAMD_RAISE(TURTLE_RETURN_BAD_ADDRESS, "invalid null argument");
+        return step_n(&error_, stepper, n, position, direction, NULL, NULL, next, NULL, step, index,
+            TAMD_STEP_COMPACT | ((direction != NULL) ? TURTLE_AMD_STEP_RESUME : 0), space);
 }
 
 enum turtle_return turtle_stepper_step_n(struct turtle_stepper * stepper, long n,
