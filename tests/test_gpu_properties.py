@@ -217,14 +217,18 @@ def test_sorted_hand_over_changes_no_bit(tmp_path):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     results = {}
-    for figure, key in (("0", "0"), ("120", "0"), ("1000000", "0"), ("400", "0"), ("120", "1"), ("0", "1"),
-                        ("1000000", "1"), ("400", "1")):
-        out = os.path.join(tmp_path, f"sort{figure}_{key}.npz")
-        env = dict(os.environ, TURTLE_AMD_SORT_LONG=figure, TURTLE_AMD_SORT_KEY=key)
+    # ... and (round 4) the trace may take its rays in the order of WHERE THEY START -- a raster of
+    # cells over the terrain, a radix sort, the passes working in arrays of the library's own and
+    # writing each ray's results to its place in the caller's (TURTLE_AMD_SPATIAL): on and off
+    for figure, key, spatial in (("0", "0", "0"), ("120", "0", "0"), ("1000000", "0", "0"), ("400", "0", "0"),
+                                 ("120", "1", "0"), ("0", "1", "0"), ("1000000", "1", "0"), ("400", "1", "0"),
+                                 ("120", "1", "1"), ("120", "0", "1"), ("0", "0", "1")):
+        out = os.path.join(tmp_path, f"sort{figure}_{key}_{spatial}.npz")
+        env = dict(os.environ, TURTLE_AMD_SORT_LONG=figure, TURTLE_AMD_SORT_KEY=key, TURTLE_AMD_SPATIAL=spatial)
         subprocess.run([sys.executable, os.path.join(here, "creep_probe.py"), out,
-                        os.path.join(tmp_path, f"work{figure}_{key}")], check=True, env=env, timeout=300)
-        results[(figure, key)] = dict(np.load(out))
-    base = results[("0", "0")]
+                        os.path.join(tmp_path, f"work{figure}_{key}_{spatial}")], check=True, env=env, timeout=300)
+        results[(figure, key, spatial)] = dict(np.load(out))
+    base = results[("0", "0", "0")]
     assert base["map_n_steps"].max() > 2000 and base["stack_n_steps"].max() > 2000
     for figure, r in results.items():
         for key, ref in base.items():

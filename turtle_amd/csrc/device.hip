@@ -2088,6 +2088,17 @@ __device__ __forceinline__ int lane_rank(ull mask)
  * a tenth of the closed form's instructions.
  * Which arithmetic a sample uses depends only on the ray's own step count and
  * positions, never on scheduling: results stay deterministic. */
+/* Where a ray's FINAL results go when the passes work on the rays in an order of their own
+ * (run_trace, k_ray_cells): the caller's arrays, at the ray's place there.  order_of == NULL: the
+ * arrays the passes work on, same place. */
+struct RayOut {
+        const int * order_of;
+        double * pos;
+        int * index;
+        double * length;
+        int * n_steps;
+};
+
 struct PhaseIO {
         const int * ids;     /* phase B: the parked ray ids (else NULL: slot == ray) */
         const ull * n_dev;   /* phase B: their number, on the device */
@@ -2114,6 +2125,13 @@ struct PhaseIO {
         int mark_at;
         float long_if;          /* A: to the front, if expected to take more further steps than this */
         int pool;               /* B: the waves of a block exchange rays through LDS (RayPool) */
+        RayOut out;             /* where a ray that ENDS in this pass leaves its results */
+        /* A, rays in an order of the library's own: a new ray comes from the caller's arrays
+         * (`out.order_of` says from which place) and leaves its direction in dir_copy for the passes
+         * that follow */
+        const double * pos_in, * dir_in;
+        const int * index_in;
+        double * dir_copy;
         unsigned char * sort_key; /* A: the key the hand-over list is ordered by before B reads it, per
                                  * place on the list (or NULL: B reads it as it was filled) */
 };
@@ -2360,8 +2378,18 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                         ray = ph.ids[(ray < n_front) ? ray : capacity - 1 - (ray - n_front)];
                                 if (MODEL) line.valid = false, line.s = 0., line.tau = kLineTau0;
                                 stopped_ = false;
-                                bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
-                                dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
+                                if (!MODEL && (ph.dir_copy != nullptr)) {
+                                        /* (the rays in the library's order: see PhaseIO) */
+                                        const long src = ph.out.order_of[ray];
+                                        bx = ph.pos_in[3 * src], by = ph.pos_in[3 * src + 1], bz = ph.pos_in[3 * src + 2];
+                                        dx = ph.dir_in[3 * src], dy = ph.dir_in[3 * src + 1], dz = ph.dir_in[3 * src + 2];
+                                        ph.dir_copy[3 * ray] = dx, ph.dir_copy[3 * ray + 1] = dy, ph.dir_copy[3 * ray + 2] = dz;
+                                        if (flags & TRACE_CARRY_MEDIUM)
+                                                index[2 * ray] = ph.index_in[2 * src], index[2 * ray + 1] = ph.index_in[2 * src + 1];
+                                } else {
+                                        bx = pos[3 * ray], by = pos[3 * ray + 1], bz = pos[3 * ray + 2];
+                                        dx = dir[3 * ray], dy = dir[3 * ray + 1], dz = dir[3 * ray + 2];
+                                }
                                 len = 0., count = 0, state = ST_INIT;
                                 if (ph.accumulate) len = length[ray], count = n_steps[ray];
                                 count0 = count;
@@ -2808,10 +2836,18 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
                                 done = true;
                         }
                         if (done) {
-                                pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
-                                index[2 * ray] = m, index[2 * ray + 1] = k;
-                                if (length) length[ray] = len;
-                                if (n_steps) n_steps[ray] = count;
+                                if (ph.out.order_of != nullptr) { /* to the caller's arrays, the ray's place there */
+                                        const long o = ph.out.order_of[ray];
+                                        ph.out.pos[3 * o] = bx, ph.out.pos[3 * o + 1] = by, ph.out.pos[3 * o + 2] = bz;
+                                        ph.out.index[2 * o] = m, ph.out.index[2 * o + 1] = k;
+                                        ph.out.length[o] = len;
+                                        ph.out.n_steps[o] = count;
+                                } else {
+                                        pos[3 * ray] = bx, pos[3 * ray + 1] = by, pos[3 * ray + 2] = bz;
+                                        index[2 * ray] = m, index[2 * ray + 1] = k;
+                                        if (length) length[ray] = len;
+                                        if (n_steps) n_steps[ray] = count;
+                                }
                                 my_rays++;
                                 my_steps += (ull)(count - count0);
                                 ray = -1;
@@ -2941,6 +2977,50 @@ __device__ __forceinline__ void trace_body(const tamd_view & v, long n,
         block_tally(stats, my_rays, my_steps, my_samples, my_capped);
 }
 
+/* Where a ray STARTS, as one byte: the cell of a 16 x 16 raster over the map or the stack's
+ * lattice that holds its origin (rays outside go to the rim's cells).  The trace then takes the
+ * rays cell by cell (run_trace: one pass of a radix sort on these keys): the 64 rays of a wave
+ * start within a few kilometres of each other and meet the same tiles, the same pages and -- for a
+ * while -- the same cache lines.  Ordering a batch's INPUT that way was worth 19 % on C3 (16 tiles,
+ * 415 MB: 25.7 -> 20.8 ms), 7 % on C4, 4 % on C5; this does it inside the library, whatever order
+ * the caller's rays come in, and leaves the caller's arrays where they are (the passes read the
+ * rays through the ordered list of their numbers). */
+#ifndef SPATIAL_CELLS
+#define SPATIAL_CELLS 16
+#endif
+#if SPATIAL_CELLS <= 16
+#define SPATIAL_KEY_T unsigned char
+#define SPATIAL_BITS 8
+#else
+#define SPATIAL_KEY_T unsigned short
+#define SPATIAL_BITS 16
+#endif
+template <int MODE>
+__global__ void k_ray_cells(tamd_view v, long n, const double * __restrict__ pos,
+    SPATIAL_KEY_T * __restrict__ key, int * __restrict__ id)
+{
+        const tamd_meta mt = v.metas[0];
+        constexpr int kCells = SPATIAL_CELLS;
+        double x0, y0, sx, sy; /* the box: longitude, latitude; cells / its extent */
+        if (MODE == TAMD_MODE_ONE_MAP) {
+                const tamd_grid & g = v.grids[mt.src];
+                x0 = g.x0, y0 = g.y0;
+                sx = kCells / (g.dx * (g.nx - 1)), sy = kCells / (g.dy * (g.ny - 1));
+        } else {
+                const tamd_stack & st = v.stacks[mt.src];
+                x0 = st.lon0, y0 = st.lat0;
+                sx = kCells / (st.dlon * st.nlon), sy = kCells / (st.dlat * st.nlat);
+        }
+        for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < n; r += (long)gridDim.x * blockDim.x) {
+                double lat, lon, alt;
+                f_to_geodetic(pos[3 * r], pos[3 * r + 1], pos[3 * r + 2], lat, lon, alt);
+                const int bx = (int)fmin(fmax((lon - x0) * sx, 0.), (double)(kCells - 1));
+                const int by = (int)fmin(fmax((lat - y0) * sy, 0.), (double)(kCells - 1)); /* (NaN: 0) */
+                key[r] = (SPATIAL_KEY_T)(by * kCells + bx);
+                id[r] = (int)r;
+        }
+}
+
 /* The least waves a SIMD the kernel must fit (registers: 512 / waves).  The lined
  * pass is bound by what the SIMD issues, with a memory wait every few steps: a
  * third wave is worth more than the few values that go to scratch for it (one
@@ -2985,7 +3065,7 @@ k_trace(tamd_view v, long n,
 template <int MODE, bool FAST, bool PAGED>
 __global__ void __launch_bounds__(256) k_cross(tamd_view v, double * __restrict__ pos,
     const double * __restrict__ dir, int * __restrict__ index, double * __restrict__ length,
-    int * __restrict__ n_steps, CrossList cross, Paging pg, ull * __restrict__ stats)
+    int * __restrict__ n_steps, CrossList cross, Paging pg, ull * __restrict__ stats, RayOut out)
 {
         constexpr bool CAN_FAULT = PAGED && (MODE != TAMD_MODE_ONE_MAP);
         OneCtx ctx;
@@ -3061,6 +3141,14 @@ __global__ void __launch_bounds__(256) k_cross(tamd_view v, double * __restrict_
                                 /* back before the step, which the next round takes again */
                                 pos[3 * r] = px - dx * ds, pos[3 * r + 1] = py - dy * ds, pos[3 * r + 2] = pz - dz * ds;
                                 pg.tentative[r] = ds;
+                        } else if (out.order_of != nullptr) { /* (RayOut: the caller's arrays) */
+                                const long o = out.order_of[r];
+                                out.pos[3 * o] = d_along<FAST>(px, dx, ds1), out.pos[3 * o + 1] = d_along<FAST>(py, dy, ds1),
+                                out.pos[3 * o + 2] = d_along<FAST>(pz, dz, ds1);
+                                out.index[2 * o] = bm, out.index[2 * o + 1] = bk;
+                                out.length[o] = length[r] + (ds + ds1);
+                                out.n_steps[o] = n_steps[r] + 1;
+                                my_rays++;
                         } else { /* [ref stepper.c:861-863] */
                                 pos[3 * r] = d_along<FAST>(px, dx, ds1), pos[3 * r + 1] = d_along<FAST>(py, dy, ds1),
                                 pos[3 * r + 2] = d_along<FAST>(pz, dz, ds1);
@@ -3867,7 +3955,8 @@ static int launch_trace(struct tamd_view view, long n, bool n_on_device, double 
  * all of n, striding over whatever there is) */
 template <int MODE, bool FAST>
 static int launch_cross(struct tamd_view view, long n, double * pos, const double * dir, int * index,
-    double * length, int * n_steps, CrossList cross, Paging pg, ull * stats)
+    double * length, int * n_steps, CrossList cross, Paging pg, ull * stats,
+    RayOut out = { nullptr, nullptr, nullptr, nullptr, nullptr })
 {
         constexpr bool CAN_PAGE = (MODE != TAMD_MODE_ONE_MAP);
         const bool paged = CAN_PAGE && (pg.faulted != nullptr);
@@ -3878,10 +3967,10 @@ static int launch_cross(struct tamd_view view, long n, double * pos, const doubl
         if (blocks > useful) blocks = useful;
         if (paged)
                 hipLaunchKernelGGL((k_cross<MODE, FAST, CAN_PAGE>), dim3((unsigned)blocks), dim3(256), 0,
-                    g_stream, view, pos, dir, index, length, n_steps, cross, pg, stats);
+                    g_stream, view, pos, dir, index, length, n_steps, cross, pg, stats, out);
         else
                 hipLaunchKernelGGL((k_cross<MODE, FAST, false>), dim3((unsigned)blocks), dim3(256), 0,
-                    g_stream, view, pos, dir, index, length, n_steps, cross, pg, stats);
+                    g_stream, view, pos, dir, index, length, n_steps, cross, pg, stats, out);
         LAUNCH_CHECK("k_cross");
         return 0;
 }
@@ -3962,6 +4051,27 @@ static int sort_hand_over(int mode, long n)
         if (value == 0) return 0;
         if (value == 1) return 1;
         return n <= ((value > 1) ? value : 4000000L);
+}
+/* Does a trace take its rays in the order of where they start (k_ray_cells)?  TURTLE_AMD_SPATIAL:
+ * 0 never, 1 always, else from that many rays on. */
+static int spatial_order(int mode, long n)
+{
+        static long value = -2;
+        if (value == -2) {
+                const char * env = getenv("TURTLE_AMD_SPATIAL");
+                value = ((env != nullptr) && (*env != 0)) ? atol(env) : -1;
+        }
+        if ((mode == TAMD_MODE_GENERIC) || (value == 0)) return 0;
+        if (value == 1) return 1;
+        /* (measured, one pass alone, off -> on: one map at 1 / 2 / 4 / 12.5 M rays 3.13 -> 3.20, 5.91 ->
+         * 5.95, 11.17 -> 10.92, 26.7 -> 26.3 ms; a 4 x 4 stack at 1 / 10 M rays 4.10 -> 4.10, 25.5 -> 22.8) */
+        return n >= ((value > 1) ? value : 3000000L);
+}
+/* the room behind the lists of a trace (internal.h, TAMD_TRACE_SORT_ROOM), on a 256-byte boundary */
+static char * sort_room_of(int * parked, long n)
+{
+        const uintptr_t at = (uintptr_t)(parked + TAMD_TRACE_SORT_INTS * n);
+        return (char *)((at + 255) & ~(uintptr_t)255);
 }
 static int drain_lanes(void)
 {
@@ -4044,10 +4154,57 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
          * filled carry a key (254) between the front's (0 .. 253) and the back's (255), so the front comes out first, in
          * order, and the back stays at the far end, where the lined pass looks for it.  For batches
          * small enough to be as long as their longest rays (sort_hand_over()). */
+        /* The rays in the order of where they start (k_ray_cells): keys and numbers into the sort's
+         * room, one pass of the radix sort.  The passes then WORK in that order -- a ray's state
+         * between the passes (position, medium, path length, step count, its direction) lives at its
+         * place in the ordered list, in arrays of the library's own -- while the caller's arrays are
+         * touched twice a ray: phase A reads a new ray from its place there, and whichever kernel
+         * ENDS a ray (k_cross for nearly all) writes its results to that place (RayOut); no pass of
+         * its own copies anything.  (Tried first: the passes working in the caller's arrays through
+         * the ordered list -- every hand-over then goes to a place of its own instead of next to
+         * its wave's: half the gain on C3, a loss on C4; and copies made by kernels of their own:
+         * 0.9 + 1.4 ms for C4's 12.5 M rays, more than the order gains there.)  Not over paged tiles
+         * (the pager's lists name rays by their place in the CALLER's arrays, round after round). */
+        RayOut out = { nullptr, nullptr, nullptr, nullptr, nullptr };
+        if constexpr (MODE != TAMD_MODE_GENERIC) {
+                if (sort_room && !again && (pg.faulted == nullptr) && spatial_order(MODE, n)) {
+                        hipcub::DoubleBuffer<SPATIAL_KEY_T> cell((SPATIAL_KEY_T *)(parked + 5 * n),
+                            (SPATIAL_KEY_T *)(parked + 6 * n));
+                        hipcub::DoubleBuffer<int> list(parked, parked + 4 * n);
+                        size_t bytes = 0;
+                        if ((hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, cell, list, (int)n, 0, SPATIAL_BITS, g_stream) ==
+                                hipSuccess) &&
+                            (bytes <= TAMD_TRACE_SORT_TEMP)) {
+                                hipLaunchKernelGGL(k_ray_cells<MODE>, dim3(grid_for(n, 256)), dim3(256), 0, g_stream,
+                                    view, n, pos, cell.Current(), list.Current());
+                                LAUNCH_CHECK("k_ray_cells");
+                                char * const room = sort_room_of(parked, n);
+                                if (hipcub::DeviceRadixSort::SortPairs((void *)room, bytes, cell, list, (int)n, 0, SPATIAL_BITS,
+                                        g_stream) != hipSuccess)
+                                        return fail("hipcub::DeviceRadixSort", hipGetLastError());
+                                /* the arrays the passes work in, and the list, which must outlive them
+                                 * (they use parked[0, n) and the sort's room again): 72 bytes a ray */
+                                char * copies = room + TAMD_TRACE_SORT_TEMP;
+                                double * const pos_s = (double *)copies;
+                                double * const dir_s = pos_s + 3 * n;
+                                double * const length_s = dir_s + 3 * n;
+                                int * const index_s = (int *)(length_s + n);
+                                int * const n_steps_s = index_s + 2 * n;
+                                int * const kept = n_steps_s + n;
+                                HIP_TRY(hipMemcpyAsync(kept, list.Current(), (size_t)n * sizeof(int),
+                                    hipMemcpyDeviceToDevice, g_stream));
+                                out.order_of = kept, out.pos = pos, out.index = index, out.length = length,
+                                out.n_steps = n_steps;
+                                a.out = out, b.out = out;
+                                a.pos_in = pos, a.dir_in = dir, a.index_in = index, a.dir_copy = dir_s;
+                                pos = pos_s, dir = dir_s, index = index_s, length = length_s, n_steps = n_steps_s;
+                        }
+                }
+        }
         const bool order = sort_room && !again && (a.n_parked_back != nullptr) && sort_hand_over(MODE, n);
         hipcub::DoubleBuffer<unsigned char> keys((unsigned char *)(parked + 5 * n), (unsigned char *)(parked + 6 * n));
         hipcub::DoubleBuffer<int> ids(parked, parked + 4 * n);
-        void * const sort_temp = (void *)(parked + TAMD_TRACE_SORT_INTS * n);
+        void * const sort_temp = (void *)sort_room_of(parked, n);
         size_t temp_bytes = 0;
         bool sorting = false;
         if (order) {
@@ -4071,7 +4228,7 @@ static int run_trace(struct tamd_view view, long n, double * pos, const double *
         if (launch_trace<MODE, true, true>(view, n, true, pos, dir, max_steps, index, length,
                 n_steps, flags | TRACE_CARRY_MEDIUM, b, stats, queue + 1 * kQ))
                 return 1;
-        return launch_cross<MODE, true>(view, n, pos, dir, index, length, n_steps, cross, pg, stats);
+        return launch_cross<MODE, true>(view, n, pos, dir, index, length, n_steps, cross, pg, stats, out);
 }
 
 /* queue: five counters (see run_trace); parked: room for 3 n ray ids and cross_ds

@@ -222,6 +222,9 @@ int tamd_k_step(struct tamd_view view, long n, double * pos,
 #define TAMD_STEP_COMPACT 0x200
 #define TAMD_TRACE_SORT_INTS 7
 #define TAMD_TRACE_SORT_TEMP ((size_t)32 << 20)
+/* ... and, behind those, TAMD_TRACE_COPY_BYTES x n bytes for the rays themselves in the order
+ * the trace takes them (position, direction, index, path length, step count) */
+#define TAMD_TRACE_COPY_BYTES 72
 int tamd_k_trace(struct tamd_view view, long n, double * pos,
     const double * dir, int max_steps, int * index, double * length,
     int * n_steps, int flags, int * parked, double * cross_ds, struct tamd_paging pg,

@@ -678,7 +678,9 @@ static int tamd_stepper_scratch(struct turtle_stepper * stepper, long n)
                 stepper->d_parked = NULL;
         }
         /* (the lists of the passes, and room to order the hand-over: internal.h) */
-        const size_t ints = ((((size_t)n * TAMD_TRACE_SORT_INTS * sizeof(int) + TAMD_TRACE_SORT_TEMP) + 255) / 256) * 256;
+        /* (+ 256: the sort's room begins at the next multiple of 256 bytes behind the ints) */
+        const size_t ints = ((((size_t)n * TAMD_TRACE_SORT_INTS * sizeof(int) + 256 + TAMD_TRACE_SORT_TEMP +
+                                  (size_t)n * TAMD_TRACE_COPY_BYTES) + 255) / 256) * 256;
         stepper->parked_capacity = 0;
         if (tamd_dev_malloc((void **)&stepper->d_parked, ints + (size_t)n * 4 * sizeof(double))) {
                 stepper->parked_capacity = -1;
