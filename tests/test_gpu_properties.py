@@ -262,3 +262,20 @@ def test_hand_over_step_moves_no_result(tmp_path):
             moved = int((r[f"{tag}_n_steps"] != base[f"{tag}_n_steps"]).sum())
             print(f"hand-over at {park}, {tag}: {moved} of {base[f'{tag}_n_steps'].size} rays take another step count")
             assert moved <= HAND_OVER_MOVED, (park, tag, moved)
+
+
+def test_odd_batch_sizes_through_every_optional_path():
+    """The trace's optional machinery -- the block's ray pool, the ordered hand-over, the rays in
+    the order of where they start -- is switched on by batch size; here ALL of it is forced on for
+    batches of 1 to 100 003 rays (odd sizes: lists and the sorts' rooms that end on no boundary, waves
+    with one ray), one map and a 2 x 2 stack, against the same batches with all of it off: the same
+    bits (scripts/exp_odd_sizes.py; up to 700 001 rays there)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "scripts", "exp_odd_sizes.py")
+    run = subprocess.run([sys.executable, script, "1", "65", "257", "4097", "100003"], capture_output=True,
+                         text=True, timeout=600)
+    print(run.stdout[-1500:])
+    assert run.returncode == 0, run.stderr[-1500:]
+    assert run.stdout.count("same bits") == 5
